@@ -1,0 +1,224 @@
+/* ptw.h — C ABI of the MI355X-native "hip" way of pt-three-ways' DoD radiance path.
+ *
+ * This header is the drop-in boundary: plain C, plain pointers and sizes, no C++ or torch
+ * types.  A host in any language binds these symbols (see INTEGRATION.md for the C++ stub a
+ * pt-three-ways maintainer would add next to `oo`/`fp`/`dod` in src/main/main.cpp:350-366,
+ * and for a ctypes stub).  Every entry point cites the reference interface it replaces;
+ * paths are relative to the reference repository root.
+ *
+ * Conventions
+ *  - All real arithmetic is IEEE binary64, as in the reference (src/math/Vec3.h:9).
+ *  - Vectors are double[3] = {x, y, z}.
+ *  - Every function returning `int` returns PTW_OK (0) or a ptw_status error code; the
+ *    message for the calling thread's last error is available from ptw_last_error().
+ *    Nothing throws across this boundary and nothing aborts the process.
+ *  - The caller owns every buffer it passes in.  Objects created by *_create are released
+ *    by the matching *_destroy.
+ *  - There is no CPU fallback: rendering entry points fail with PTW_ERR_NO_DEVICE when no
+ *    gfx950-class HIP device is usable.
+ */
+#ifndef PTW_H_
+#define PTW_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTW_ABI_VERSION 1
+
+typedef enum ptw_status {
+  PTW_OK = 0,
+  PTW_ERR_INVALID = 1,       /* bad argument (null pointer, non-positive size, ...)            */
+  PTW_ERR_NO_DEVICE = 2,     /* no usable HIP device / extension built without one             */
+  PTW_ERR_HIP = 3,           /* a HIP runtime call or kernel launch failed                     */
+  PTW_ERR_IO = 4,            /* std::runtime_error("Unable to open ...") in the reference      */
+  PTW_ERR_PARSE = 5,         /* OBJ/MTL parse error (message mirrors the reference's text)     */
+  PTW_ERR_UNKNOWN_SCENE = 6, /* "Unknown scene <name>", src/main/main.cpp:308                  */
+  PTW_ERR_SIZE_MISMATCH = 7, /* std::logic_error in ArrayOutput::operator+=, ArrayOutput.cpp:50 */
+  PTW_ERR_UNSUPPORTED = 8
+} ptw_status;
+
+/* How random numbers are assigned to samples.
+ *  SEQUENTIAL — the reference's policy, bit-compatible stream: one std::mt19937 per pass,
+ *               seeded `seed + pass`, consumed by the pixels of that pass in row-major order
+ *               with a data-dependent number of draws per pixel (src/dod/Scene.cpp:208-217).
+ *               Results match the reference DoD renderer at matched seed.
+ *  PERPIXEL   — one independent counter-seeded stream per (pass, pixel); pixels become
+ *               independent, so image tiles can be sharded.  Not seed-matched with the
+ *               reference (same estimator, different random numbers). */
+typedef enum ptw_rng_policy { PTW_RNG_SEQUENTIAL = 0, PTW_RNG_PERPIXEL = 1 } ptw_rng_policy;
+
+/* MaterialSpec, src/util/MaterialSpec.h:7-12 (same field order, 72 bytes). */
+typedef struct ptw_material {
+  double emission[3];
+  double diffuse[3];
+  double index_of_refraction;      /* default 1.0 */
+  double reflectivity;             /* default -1 => Fresnel-ish reflectance, Norm3.cpp:7-24 */
+  double reflection_cone_angle_rad; /* default 0.0 */
+} ptw_material;
+
+/* What dod::Scene holds after the SceneBuilder calls (src/dod/Scene.h:22-31), flattened.
+ * Primitive order is insertion order; it is the nearest-hit tie-break order. */
+typedef struct ptw_scene_view {
+  uint32_t num_triangles;
+  uint32_t num_spheres;
+  uint32_t num_materials;
+  uint32_t reserved;
+  const double *tri_vertices;      /* [num_triangles][3 vertices][3]                        */
+  const uint32_t *tri_material;    /* [num_triangles] index into materials                  */
+  const double *sph_centre_radius; /* [num_spheres][4] = centre xyz, radius (not squared)   */
+  const uint32_t *sph_material;    /* [num_spheres]                                         */
+  const ptw_material *materials;   /* [num_materials]                                       */
+  double environment[3];           /* Scene::environment_, default (0,0,0)                  */
+} ptw_scene_view;
+
+/* Everything Camera keeps private (src/math/Camera.h:11-18). */
+typedef struct ptw_camera {
+  double centre[3];
+  double axis_x[3], axis_y[3], axis_z[3]; /* OrthoNormalBasis::fromZY(dir, up)              */
+  double aspect_ratio;                    /* width / height                                 */
+  double camera_plane_dist;               /* 1 / tan(vfov * pi / 360)                       */
+  double reciprocal_height;
+  double reciprocal_width;
+  double aperture_radius;                 /* 0 => pinhole: 2 draws per primary ray, else 4  */
+  double focal_distance;
+} ptw_camera;
+
+/* RenderParams (src/util/RenderParams.h:3-13) plus what the hip way adds. */
+typedef struct ptw_render_params {
+  int32_t width;                 /* default 1920 */
+  int32_t height;                /* default 1080 */
+  int32_t preview;               /* default 0    */
+  int32_t samples_per_pixel;     /* default 40; the number of passes rendered AND kept      */
+  int32_t max_depth;             /* default 5    */
+  int32_t first_bounce_u;        /* default 4    */
+  int32_t first_bounce_v;        /* default 4    */
+  int32_t seed;                  /* pass k uses mt19937(uint32(seed + first_pass + k))      */
+  int32_t first_pass;            /* default 0: index of the first pass (multi-GPU / resume) */
+  int32_t rng_policy;            /* ptw_rng_policy                                          */
+  /* Pixel window for PERPIXEL tile sharding: rows [row_begin, row_end) are rendered; the
+   * output buffers always describe the full width x height frame.  0,0 => all rows.        */
+  int32_t row_begin;
+  int32_t row_end;
+  int32_t device;                /* HIP device ordinal for ptw_render()                     */
+  int32_t reserved[3];
+} ptw_render_params;
+
+/* Progress callback, the analogue of `updateFunc(output)` (src/dod/Scene.cpp:245) and of
+ * Progressifier (src/util/Progressifier.cpp:11-21): called on the calling thread between
+ * device launches with the number of finished samples.  Return non-zero to cancel. */
+typedef int (*ptw_progress_fn)(void *user, uint64_t samples_done, uint64_t samples_total);
+
+const char *ptw_last_error(void);
+int ptw_abi_version(void);
+void ptw_default_params(ptw_render_params *out);           /* RenderParams.h:3-13 defaults */
+void ptw_default_material(ptw_material *out);              /* MaterialSpec.h:8-12 defaults */
+
+/* ---- MaterialSpec factories, src/util/MaterialSpec.h:13-32 ------------------------------ */
+void ptw_material_diffuse(const double colour[3], ptw_material *out);
+void ptw_material_specular(const double colour[3], double index, ptw_material *out);
+void ptw_material_light(const double colour[3], ptw_material *out);
+void ptw_material_glossy(const double colour[3], double index, double cone_degrees,
+                         ptw_material *out);
+void ptw_material_reflective(const double colour[3], double reflectivity, double cone_degrees,
+                             ptw_material *out);
+
+/* ---- SceneBuilder concept, src/dod/Scene.h:37-42 and src/dod/Scene.cpp:181-195 ---------- */
+typedef struct ptw_scene ptw_scene;
+int ptw_scene_create(ptw_scene **out);
+void ptw_scene_destroy(ptw_scene *scene);
+int ptw_scene_add_triangle(ptw_scene *scene, const double v0[3], const double v1[3],
+                           const double v2[3], const ptw_material *material);
+int ptw_scene_add_sphere(ptw_scene *scene, const double centre[3], double radius,
+                         const ptw_material *material);
+int ptw_scene_set_environment(ptw_scene *scene, const double colour[3]);
+/* loadObjFile + DirRelativeOpener, src/util/ObjLoaderImpl.h:55-103, src/main/main.cpp:27-38.
+ * `obj_path` is opened directly; `mtllib` names are resolved relative to `mtl_dir`. */
+int ptw_scene_load_obj(ptw_scene *scene, const char *obj_path, const char *mtl_dir);
+/* Same parser fed from memory (the reference's tests feed strings, ObjLoaderTests.cpp:29-35);
+ * `mtl_text` may be NULL, in which case any `mtllib` directive fails like the reference's
+ * ThrowingObjLoaderOpener. */
+int ptw_scene_load_obj_text(ptw_scene *scene, const char *obj_text, const char *mtl_text);
+/* createScene(sb, name, params), src/main/main.cpp:291-309: the built-in scenes "cornell",
+ * "suzanne", "ce", "single-sphere", "multi-sphere", "example1", "bbc-owl".  OBJ-backed scenes
+ * read `<scenes_dir>/<file>` (the reference hard-codes "scenes"). */
+int ptw_scene_build_named(ptw_scene *scene, const char *name, const char *scenes_dir,
+                          int32_t width, int32_t height, ptw_camera *camera_out);
+/* Borrowed view, valid until the scene is modified or destroyed. */
+int ptw_scene_view_of(const ptw_scene *scene, ptw_scene_view *out);
+
+/* ---- Camera ctor / setFocus, src/math/Camera.h:40-51 ------------------------------------ */
+int ptw_camera_look_at(const double eye[3], const double look_at[3], const double up[3],
+                       int32_t width, int32_t height, double vertical_fov_degrees,
+                       ptw_camera *out);
+int ptw_camera_set_focus(ptw_camera *camera, const double focal_point[3],
+                         double aperture_radius);
+
+/* ---- dod::Scene::render, src/dod/Scene.h:44-46 / src/dod/Scene.cpp:197-254 ---------------
+ * Renders `samples_per_pixel` passes on HIP device `params->device` and ADDS them into the
+ * caller's ArrayOutput-shaped buffers: rgb_sum[(x + y*width)*3 + c] += sample radiance,
+ * counts[x + y*width] += 1 per pass (ArrayOutput::addSamples / operator+=,
+ * src/util/ArrayOutput.cpp:39-56).  Unlike the reference's scheduler (Scene.cpp:251) no
+ * launched pass is dropped: exactly samples_per_pixel passes are accumulated, in pass order. */
+int ptw_render(const ptw_scene_view *scene, const ptw_camera *camera,
+               const ptw_render_params *params, double *rgb_sum, uint32_t *counts,
+               ptw_progress_fn progress, void *user);
+
+/* ---- Device-resident form of the same call (HBM in, HBM out) ---------------------------- */
+typedef struct ptw_context ptw_context;
+int ptw_context_create(int32_t device, ptw_context **out);
+void ptw_context_destroy(ptw_context *ctx);
+/* Upload + per-primitive precompute (the work of addTriangle/addSphere, Scene.cpp:181-195). */
+int ptw_context_set_scene(ptw_context *ctx, const ptw_scene_view *scene);
+/* Enqueue the render on `hip_stream` (a hipStream_t, NULL = default stream).  d_rgb_sum and
+ * d_counts are DEVICE pointers to width*height*3 doubles / width*height uint32 and are
+ * accumulated into.  Asynchronous: the caller synchronises the stream.  If d_words is not
+ * NULL it receives, per pass and pixel ([pass][y][x], uint32), the number of 32-bit RNG words
+ * that sample consumed (parity instrumentation; SEQUENTIAL and PERPIXEL). */
+int ptw_context_render(ptw_context *ctx, const ptw_camera *camera,
+                       const ptw_render_params *params, void *d_rgb_sum, void *d_counts,
+                       void *d_words, void *hip_stream);
+/* Per-kernel timing gathered with hipEvents on the launch stream when enabled. */
+typedef struct ptw_kernel_stats {
+  uint64_t trace_launches;   /* launches of the radiance kernel since the last reset   */
+  double trace_ms;           /* summed device time of those launches                   */
+  uint64_t resolve_launches; /* launches of the pass-ordered accumulate kernel         */
+  double resolve_ms;
+  uint64_t samples;          /* samples traced by those launches                       */
+  uint64_t rays;             /* intersect() calls made by those launches (0 if unknown) */
+} ptw_kernel_stats;
+int ptw_context_enable_stats(ptw_context *ctx, int32_t enable);
+/* Synchronises the events it reads. */
+int ptw_context_get_stats(ptw_context *ctx, ptw_kernel_stats *out, int32_t reset);
+
+/* Batch form of Scene::intersect (src/dod/Scene.cpp:115-122) for known-answer tests:
+ * rays[n][6] = origin, direction (direction already normalised) -> hit[n]: distance (or -1
+ * for a miss), inside flag, position, normal, material index (as doubles: 9 per ray). */
+int ptw_context_intersect(ptw_context *ctx, const double *rays, uint64_t n, double *hits_out);
+
+/* ---- ArrayOutput surface, src/util/ArrayOutput.cpp ------------------------------------- */
+/* .raw: header {u32 signature=1, version=1, height, width} then per pixel 3 x f64 sum +
+ * u32 count (ArrayOutput.cpp:21-28,65-81). */
+int ptw_raw_save(const char *path, int32_t width, int32_t height, const double *rgb_sum,
+                 const uint32_t *counts);
+int ptw_raw_read_header(const char *path, int32_t *width, int32_t *height);
+/* Adds the file's sums/counts into the buffers (ArrayOutput::load + operator+=,
+ * ArrayOutput.cpp:83-110, raw_to_png.cpp:39-58). */
+int ptw_raw_load_accumulate(const char *path, int32_t width, int32_t height, double *rgb_sum,
+                            uint32_t *counts);
+/* ArrayOutput::pixelAt for every pixel: lround(pow(clamp(mean,0,1), 1/2.2) * 255)
+ * (ArrayOutput.cpp:9-12,30-35); rgb8_out is width*height*3 bytes. */
+int ptw_pixels_rgb8(int32_t width, int32_t height, const double *rgb_sum,
+                    const uint32_t *counts, uint8_t *rgb8_out);
+/* PngWriter (src/main/PngWriter.cpp): 8-bit RGB, non-interlaced PNG. */
+int ptw_png_save(const char *path, int32_t width, int32_t height, const uint8_t *rgb8);
+/* ArrayOutput::totalSamples, ArrayOutput.cpp:58-63. */
+uint64_t ptw_total_samples(int32_t width, int32_t height, const uint32_t *counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTW_H_ */

@@ -1,0 +1,195 @@
+// ptw_device.h — device-side fp64 math of the hip way (gfx950 / CDNA4, wave64).
+//
+// Restates, for one GPU lane, every value-type function the reference's radiance path calls
+// (src/math/*.h, src/math/Samples.cpp, src/math/Norm3.cpp) with the reference's operation
+// order.  The compiler may contract a*b+c into v_fma_f64 (one rounding instead of two); that
+// is within the reference's own build-to-build spread (its CMakeLists.txt:21 builds with
+// -march=native -funsafe-math-optimizations, i.e. with FMA contraction), and parity is
+// asserted to 1e-12 relative with bit-exact RNG word counts (tests/test_gpu_parity.py).
+// sqrt and division are IEEE correctly rounded on gfx950 (no fast-math flags are used).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ptwd {
+
+constexpr double kEpsilon = 0.000000001; // src/math/Epsilon.h:3
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kInf = __builtin_huge_val();
+
+struct d3 {
+  double x, y, z;
+};
+
+__device__ __forceinline__ d3 mk(double x, double y, double z) { return d3{x, y, z}; }
+__device__ __forceinline__ d3 operator+(d3 a, d3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ d3 operator-(d3 a, d3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ d3 operator-(d3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ d3 operator*(d3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ d3 operator*(d3 a, d3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+// Vec3::dot, src/math/Vec3.h:81-83
+__device__ __forceinline__ double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// Vec3::cross, src/math/Vec3.h:85-90
+__device__ __forceinline__ d3 cross(d3 a, d3 b) {
+  return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// Vec3::normalised = *this / length(): multiply by 1.0 / sqrt(dot) (Vec3.h:51-54, impl.h:5-7)
+__device__ __forceinline__ d3 normalised(d3 a) {
+  const double reciprocal = 1.0 / __builtin_sqrt(dot(a, a));
+  return mk(a.x * reciprocal, a.y * reciprocal, a.z * reciprocal);
+}
+
+struct Basis {
+  d3 x, y, z;
+};
+// OrthoNormalBasis::fromZ, src/math/OrthoNormalBasis.cpp:44-51
+__device__ __forceinline__ Basis basisFromZ(d3 z) {
+  const bool coincident = __builtin_fabs(z.x * 1.0 + z.y * 0.0 + z.z * 0.0) > 0.9999;
+  const d3 a = coincident ? mk(0, 1, 0) : mk(1, 0, 0);
+  Basis b;
+  b.x = normalised(cross(a, z));
+  b.y = normalised(cross(z, b.x));
+  b.z = z;
+  return b;
+}
+// OrthoNormalBasis::transform, src/math/OrthoNormalBasis.h:18-20
+__device__ __forceinline__ d3 transform(const Basis &b, d3 p) {
+  return (b.x * p.x + b.y * p.y) + b.z * p.z;
+}
+
+// Norm3::reflect, src/math/Norm3.impl.h:41-44: incoming - (n * 2) * n.dot(incoming)
+__device__ __forceinline__ d3 reflect(d3 n, d3 incoming) {
+  return incoming - (n * 2.0) * dot(n, incoming);
+}
+
+// Norm3::reflectance, src/math/Norm3.cpp:7-24.  rParallel is the same expression as
+// rPerpendicular upstream, so the result is (r*r + r*r) / 2.  iorRatio = iorFrom / iorTo is
+// passed in (the host precomputes 1/ior with the same correctly rounded division).
+__device__ __forceinline__ double reflectance(d3 n, d3 incoming, double iorFrom, double iorTo,
+                                              double iorRatio) {
+  const double cosThetaI = -dot(n, incoming);
+  const double sinThetaTSquared = iorRatio * iorRatio * (1 - cosThetaI * cosThetaI);
+  if (sinThetaTSquared > 1) return 1.0;
+  const double cosThetaT = __builtin_sqrt(1 - sinThetaTSquared);
+  const double r =
+      (iorFrom * cosThetaI - iorTo * cosThetaT) / (iorFrom * cosThetaI + iorTo * cosThetaT);
+  return (r * r + r * r) / 2;
+}
+
+// hemisphereSample, src/math/Samples.cpp:21-30
+__device__ __forceinline__ d3 hemisphereSample(const Basis &basis, double u, double v) {
+  const double theta = (2 * kPi) * u;
+  const double radius = __builtin_sqrt(v);
+  double s, c;
+  sincos(theta, &s, &c);
+  return normalised(transform(basis, mk(c * radius, s * radius, __builtin_sqrt(1 - v))));
+}
+
+// coneSample, src/math/Samples.cpp:6-19
+__device__ __forceinline__ d3 coneSample(d3 direction, double coneTheta, double u, double v) {
+  if (coneTheta < kEpsilon) return direction;
+  coneTheta = coneTheta * (1.0 - (2.0 * acos(u) / kPi));
+  double radius, zScale;
+  sincos(coneTheta, &radius, &zScale);
+  const double randomTheta = v * 2 * kPi;
+  double s, c;
+  sincos(randomTheta, &s, &c);
+  const Basis basis = basisFromZ(direction);
+  return normalised(transform(basis, mk(c * radius, s * radius, zScale)));
+}
+
+// ---- wave64 cross-lane helpers ----------------------------------------------------------
+__device__ __forceinline__ int lo32(double x) { return __double2loint(x); }
+__device__ __forceinline__ int hi32(double x) { return __double2hiint(x); }
+__device__ __forceinline__ double mk64(int lo, int hi) { return __hiloint2double(hi, lo); }
+
+__device__ __forceinline__ double readLane(double x, int lane) {
+  return mk64(__builtin_amdgcn_readlane(lo32(x), lane), __builtin_amdgcn_readlane(hi32(x), lane));
+}
+__device__ __forceinline__ double readFirstLane(double x) {
+  return mk64(__builtin_amdgcn_readfirstlane(lo32(x)), __builtin_amdgcn_readfirstlane(hi32(x)));
+}
+__device__ __forceinline__ bool uniformBool(bool b) {
+  return __builtin_amdgcn_readfirstlane(static_cast<int>(b)) != 0;
+}
+
+template <int Ctrl, int RowMask>
+__device__ __forceinline__ double dppMove(double x) {
+  // lanes the DPP pattern does not feed keep their own value (old = x, bound_ctrl = 0)
+  const int lo = __builtin_amdgcn_update_dpp(lo32(x), lo32(x), Ctrl, RowMask, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(hi32(x), hi32(x), Ctrl, RowMask, 0xf, false);
+  return mk64(lo, hi);
+}
+template <int Ctrl, int RowMask>
+__device__ __forceinline__ unsigned dppMoveU(unsigned x) {
+  return static_cast<unsigned>(__builtin_amdgcn_update_dpp(
+      static_cast<int>(x), static_cast<int>(x), Ctrl, RowMask, 0xf, false));
+}
+
+// Minimum over the 64 lanes of a wave, returned wave-uniform.  DPP row shifts inside each
+// 16-lane row, then row_bcast15 / row_bcast31 (gfx9-family DPP) into lane 63.
+__device__ __forceinline__ double waveMin(double x) {
+  x = fmin(x, dppMove<0x111, 0xf>(x)); // row_shr:1
+  x = fmin(x, dppMove<0x112, 0xf>(x)); // row_shr:2
+  x = fmin(x, dppMove<0x114, 0xf>(x)); // row_shr:4
+  x = fmin(x, dppMove<0x118, 0xf>(x)); // row_shr:8
+  x = fmin(x, dppMove<0x142, 0xa>(x)); // row_bcast:15 -> rows 1,3
+  x = fmin(x, dppMove<0x143, 0xc>(x)); // row_bcast:31 -> rows 2,3
+  return readLane(x, 63);
+}
+__device__ __forceinline__ unsigned waveMinU(unsigned x) {
+  x = min(x, dppMoveU<0x111, 0xf>(x));
+  x = min(x, dppMoveU<0x112, 0xf>(x));
+  x = min(x, dppMoveU<0x114, 0xf>(x));
+  x = min(x, dppMoveU<0x118, 0xf>(x));
+  x = min(x, dppMoveU<0x142, 0xa>(x));
+  x = min(x, dppMoveU<0x143, 0xc>(x));
+  return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(x), 63));
+}
+
+// ---- std::mt19937 pieces ------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mtTwist(uint32_t cur, uint32_t next, uint32_t far) {
+  const uint32_t y = (cur & 0x80000000u) | (next & 0x7fffffffu);
+  return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ __forceinline__ uint32_t mtTemper(uint32_t z) {
+  z ^= (z >> 11);
+  z ^= (z << 7) & 0x9d2c5680u;
+  z ^= (z << 15) & 0xefc60000u;
+  z ^= (z >> 18);
+  return z;
+}
+// std::generate_canonical<double,53> for a 32-bit engine (libstdc++ random.tcc:3348-3380):
+// (w0 + w1 * 2^32) rounded once to nearest-even, / 2^64, clamped below 1.
+__device__ __forceinline__ double canonicalFromWords(uint32_t w0, uint32_t w1) {
+  const double sum =
+      __builtin_fma(static_cast<double>(w1), 4294967296.0, static_cast<double>(w0));
+  double ret = sum * 0x1p-64;
+  if (ret >= 1.0) ret = 0x1.fffffffffffffp-1; // nextafter(1.0, 0.0)
+  return ret;
+}
+
+// sfc32, the PERPIXEL policy stream (see oracle/ptw_oracle.c for the definition).
+struct Sfc32 {
+  uint32_t a, b, c, counter;
+  __device__ __forceinline__ uint32_t next() {
+    const uint32_t t = a + b + counter;
+    counter += 1u;
+    a = b ^ (b >> 9);
+    b = c + (c << 3);
+    c = ((c << 21) | (c >> 11)) + t;
+    return t;
+  }
+  __device__ __forceinline__ void seed(uint32_t passSeed, uint32_t pixelIndex) {
+    a = pixelIndex;
+    b = passSeed;
+    c = 0x9E3779B9u;
+    counter = 1u;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) (void)next();
+  }
+};
+
+} // namespace ptwd

@@ -1,0 +1,52 @@
+// ptw_kernels.h — device data layout and kernel launchers of the hip way.
+#pragma once
+
+#include "../../include/ptw.h"
+#include "ptw_layout.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ptw {
+
+struct TraceParams {
+  ptw_camera cam;
+  double env[3];
+  double invFirstBounce; // 1.0 / (fbU * fbV)
+  double invU, invV;     // 1.0 / fbU, 1.0 / fbV (used when they are powers of two)
+  uint32_t ntri, nsph;
+  int32_t width, height;
+  int32_t maxDepth, fbU, fbV, preview;
+  int32_t uPow2, vPow2;
+  int32_t rngPolicy;
+  uint32_t passSeedBase; // uint32(seed + first_pass): pass k uses passSeedBase + k
+  uint32_t pixBegin;     // first pixel (row-major index) of this launch's band
+  uint32_t pixCount;     // pixels in the band
+  uint32_t npix;         // width * height
+  uint32_t npass;
+};
+
+struct TraceBuffers {
+  const double *triGeom;     // [ntri][9]: v0, e1 = v1 - v0, e2 = v2 - v0
+  const TriShade *triShade;  // [ntri]
+  const SphereRec *spheres;  // [nsph]
+  uint32_t *mtState;         // [npass][624] raw mt19937 state (SEQUENTIAL)
+  uint32_t *mtPos;           // [npass] next canonical double (0..312; 312 = regenerate)
+  double *stage;             // [npass][pixCount][3] this band's per-pass radiance
+  uint32_t *words;           // optional [npass][npix]
+  unsigned long long *rays;  // optional [npass] intersect() call counters
+};
+
+// SEQUENTIAL policy: one workgroup per pass walks the band's pixels in row-major order.
+hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hipStream_t stream);
+// PERPIXEL policy: one lane per (pass, pixel) sample.
+hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipStream_t stream);
+// rgbSum[pix] += sum over passes (in pass order) of stage[pass][pix]; counts[pix] += npass.
+hipError_t launchResolve(const double *stage, uint32_t npass, uint32_t pixBegin, uint32_t pixCount,
+                         double *rgbSum, uint32_t *counts, hipStream_t stream);
+// Scene::intersect for a batch of rays (known-answer tests).
+hipError_t launchIntersectBatch(const TraceParams &p, const TraceBuffers &b, const double *rays,
+                                uint64_t n, double *hitsOut, hipStream_t stream);
+
+} // namespace ptw

@@ -1,0 +1,703 @@
+// ptw_kernels.hip — hand-written HIP kernels (gfx950, wave64) for pt-three-ways' DoD radiance
+// path: dod::Scene::render -> radiance -> intersect* (src/dod/Scene.cpp).
+//
+// Two kernels trace, one accumulates:
+//
+//  traceSequential<SLOTS, WAVES>   SEQUENTIAL RNG policy (bit-compatible with the reference's
+//      per-pass std::mt19937 stream).  Within a pass the reference consumes one RNG stream
+//      across pixels in row-major order with a data-dependent number of draws per pixel
+//      (Scene.cpp:211-217), so pixels of one pass are serially dependent.  Parallelism is
+//      therefore (a) across passes: ONE WORKGROUP PER PASS, and (b) inside a ray's brute-force
+//      nearest-hit search: every lane owns SLOTS triangles, resident in VGPRs for the whole
+//      launch (v0, e1, e2 as 9 doubles each; zero memory traffic in the hot loop), tests them
+//      against the wave-uniform ray, and a DPP min-reduction (plus one LDS exchange when
+//      WAVES > 1) picks the nearest hit with the reference's tie-break (lowest insertion
+//      index; spheres before triangles).  Everything after the reduction (shading, sampling,
+//      RNG) is workgroup-uniform.  mt19937 lives in LDS: 624 raw words plus the 312 canonical
+//      doubles they yield, regenerated 64 lanes at a time, so a draw is one LDS broadcast read.
+//
+//  tracePerPixel                   PERPIXEL policy: one lane per (pass, pixel) sample, sfc32
+//      stream per sample, triangles streamed wave-uniformly (scalar loads, SGPR operands).
+//
+//  resolve                         adds the staged per-pass radiance into the fp64 running
+//      sums in pass order (ArrayOutput::operator+=, src/util/ArrayOutput.cpp:48-56) so the
+//      accumulation order - and therefore the rounding - is that of `--max-cpus 1`.
+#include "ptw_device.h"
+#include "ptw_kernels.h"
+
+namespace ptw {
+using namespace ptwd;
+
+namespace {
+
+constexpr uint32_t kMiss = 0xffffffffu;
+
+struct HitKey {
+  double t;     // distance along the ray (+inf on a miss)
+  uint32_t idx; // combined primitive index: spheres [0, nsph), triangles nsph + k; kMiss
+  double det;   // Moller-Trumbore determinant of the winning triangle (backface test)
+};
+
+// What radiance() needs to know about the surface at a hit (Scene.cpp:135-152).
+struct Surface {
+  d3 pos;
+  d3 normal;
+  Basis basis;
+  double reflectivity;
+  d3 emission;
+  d3 diffuse;
+  double coneAngle;
+};
+
+__device__ __forceinline__ d3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
+
+// One Moller-Trumbore test, Scene.cpp:62-98, against a triangle given as v0, e1, e2.
+// Updates (bestT, bestIdx, bestDet) when this triangle is a strictly nearer acceptable hit.
+__device__ __forceinline__ void testTriangle(d3 o, d3 d, d3 v0, d3 e1, d3 e2, uint32_t idx,
+                                             double &bestT, uint32_t &bestIdx, double &bestDet) {
+  const d3 pVec = cross(d, e2);
+  const double det = dot(e1, pVec);
+  if (__builtin_fabs(det) < kEpsilon) return;
+  const double invDet = 1.0 / det;
+  const d3 tVec = o - v0;
+  const double u = dot(tVec, pVec) * invDet;
+  const d3 qVec = cross(tVec, e1);
+  const double v = dot(d, qVec) * invDet;
+  if ((u < 0.0) | (u > 1.0) | (v < 0.0) | (u + v > 1)) return;
+  const double t = dot(e2, qVec) * invDet;
+  if (t > kEpsilon && t < bestT) {
+    bestT = t;
+    bestIdx = idx;
+    bestDet = det;
+  }
+}
+
+// One sphere test, Scene.cpp:17-35.
+__device__ __forceinline__ void testSphere(d3 o, d3 d, d3 centre, double radiusSquared,
+                                           uint32_t idx, double &bestT, uint32_t &bestIdx) {
+  const d3 op = centre - o;
+  const double b = dot(op, d);
+  double determinant = b * b - dot(op, op) + radiusSquared;
+  if (determinant < 0) return;
+  determinant = __builtin_sqrt(determinant);
+  const double minusT = b - determinant;
+  const double plusT = b + determinant;
+  if (minusT < kEpsilon && plusT < kEpsilon) return;
+  const double t = minusT > kEpsilon ? minusT : plusT;
+  if (t < bestT) {
+    bestT = t;
+    bestIdx = idx;
+  }
+}
+
+// Builds the Surface for a hit.  `uniform` callers pass a wave-uniform key so the record
+// loads become scalar loads.
+__device__ __forceinline__ Surface makeSurface(const TraceParams &p, const TriShade *triShade,
+                                               const SphereRec *spheres, const HitKey &k, d3 o,
+                                               d3 d) {
+  Surface s;
+  s.pos = o + d * k.t; // Ray::positionAlong, Ray.h:25-27
+  double ior, invIor, reflectivity;
+  bool inside;
+  if (k.idx >= p.nsph) {
+    const TriShade &r = triShade[k.idx - p.nsph];
+    const bool backfacing = k.det < kEpsilon; // Scene.cpp:107
+    const d3 n = ld3(r.normal), bx = ld3(r.basisX);
+    s.normal = backfacing ? -n : n;
+    s.basis.x = backfacing ? -bx : bx;
+    s.basis.y = ld3(r.basisY);
+    s.basis.z = s.normal;
+    s.emission = ld3(r.emission);
+    s.diffuse = ld3(r.diffuse);
+    s.coneAngle = r.coneAngle;
+    ior = r.ior, invIor = r.invIor, reflectivity = r.reflectivity;
+    inside = backfacing;
+  } else {
+    const SphereRec &r = spheres[k.idx];
+    d3 n = normalised(s.pos - ld3(r.centre)); // Scene.cpp:40-44
+    inside = dot(n, d) > 0;
+    if (inside) n = -n;
+    s.normal = n;
+    s.basis = basisFromZ(n);
+    s.emission = ld3(r.emission);
+    s.diffuse = ld3(r.diffuse);
+    s.coneAngle = r.coneAngle;
+    ior = r.ior, invIor = r.invIor, reflectivity = r.reflectivity;
+  }
+  // Scene.cpp:140-146
+  const double iorFrom = inside ? ior : 1.0;
+  const double iorTo = inside ? 1.0 : ior;
+  const double iorRatio = inside ? ior : invIor; // ior / 1.0 == ior ; 1.0 / ior
+  s.reflectivity =
+      reflectivity < 0 ? reflectance(s.normal, d, iorFrom, iorTo, iorRatio) : reflectivity;
+  return s;
+}
+
+// Camera::rayFromUnit / randomRay, src/math/Camera.h:20-37,54-60.  r0..r3 are canonical
+// draws in stream order (r2, r3 unused for a pinhole camera).
+__device__ __forceinline__ void cameraRay(const ptw_camera &c, int px, int py, double r0,
+                                          double r1, double r2, double r3, d3 &o, d3 &d) {
+  const double x0 = (px + r0) * c.reciprocal_width;
+  const double y0 = (py + r1) * c.reciprocal_height;
+  const double x = 2 * x0 - 1, y = 2 * y0 - 1;
+  const d3 ax = ld3(c.axis_x), ay = ld3(c.axis_y), az = ld3(c.axis_z), centre = ld3(c.centre);
+  const d3 xContrib = (ax * -x) * c.aspect_ratio;
+  const d3 yContrib = ay * -y;
+  const d3 zContrib = az * c.camera_plane_dist;
+  const d3 direction = normalised((xContrib + yContrib) + zContrib);
+  if (c.aperture_radius == 0) {
+    o = centre;
+    d = direction;
+    return;
+  }
+  const d3 focalPoint = centre + direction * c.focal_distance;
+  const double angle = r2 * (2 * kPi - 0) + 0;      // uniform_real_distribution(0, 2*pi)
+  const double radius = r3 * (c.aperture_radius - 0) + 0;
+  double sn, cs;
+  sincos(angle, &sn, &cs);
+  const d3 origin = (centre + (ax * cs) * radius) + (ay * sn) * radius;
+  o = origin;
+  d = normalised(focalPoint - origin); // Ray::fromTwoPoints, Ray.h:12-15
+}
+
+// -----------------------------------------------------------------------------------------
+// The radiance recursion of Scene.cpp:124-179 as an iteration, generic over the execution
+// context CTX, which supplies:
+//   double draw()                          next canonical double of this sample's stream
+//   HitKey intersect(d3 o, d3 d)           Scene::intersect (nearest hit, reference tie-break)
+//   bool   branch(bool)                    the condition (made wave-uniform where it is)
+//   void   push(int level, E, D, refl) / Level top(int level)   the per-depth (E, T) stack
+// The recursion L_d = E_d + T_d * L_{d+1} is folded innermost-first, as the reference
+// evaluates it, so the rounding sequence is the same.
+// -----------------------------------------------------------------------------------------
+struct Level {
+  d3 emission;
+  d3 diffuse;
+  bool reflective;
+};
+
+template <typename CTX>
+__device__ __forceinline__ bool scatter(CTX &ctx, const Surface &s, d3 dirIn, double u, double v,
+                                        double pDraw, d3 &dirOut) {
+  if (ctx.branch(pDraw < s.reflectivity)) { // Scene.cpp:163-168
+    dirOut = coneSample(reflect(s.normal, dirIn), s.coneAngle, u, v);
+    return true;
+  }
+  dirOut = hemisphereSample(s.basis, u, v); // Scene.cpp:169-175
+  return false;
+}
+
+// radiance(rng, ray, depth >= 1, ...) for the single-sample levels.
+template <typename CTX>
+__device__ __forceinline__ d3 radianceChain(CTX &ctx, const TraceParams &p,
+                                            const TriShade *triShade, const SphereRec *spheres,
+                                            d3 o, d3 d) {
+  int nlev = 0;
+  d3 L;
+  for (int depth = 1;; ++depth) {
+    if (depth >= p.maxDepth) { // Scene.cpp:128
+      L = mk(0, 0, 0);
+      break;
+    }
+    const HitKey k = ctx.intersect(o, d);
+    if (ctx.branch(k.idx == kMiss)) { // Scene.cpp:131-133
+      L = ld3(p.env);
+      break;
+    }
+    const Surface s = makeSurface(p, triShade, spheres, k, o, d);
+    // numUSamples == numVSamples == 1: (0 + xi) / 1.0 == xi exactly
+    const double u = ctx.draw();
+    const double v = ctx.draw();
+    const double pd = ctx.draw();
+    d3 nd;
+    const bool refl = scatter(ctx, s, d, u, v, pd, nd);
+    ctx.push(nlev++, s.emission, s.diffuse, refl);
+    o = s.pos;
+    d = nd;
+  }
+  // fold: result = 0 + (E + T * child); result / 1 (both exact no-ops on the value)
+  for (int i = nlev - 1; i >= 0; --i) {
+    const Level lv = ctx.top(i);
+    L = ctx.branch(lv.reflective) ? lv.emission + L : lv.emission + lv.diffuse * L;
+  }
+  return L;
+}
+
+// radiance(rng, ray, 0, renderParams): the depth-0 level with its fbU x fbV fan-out.
+template <typename CTX>
+__device__ __forceinline__ d3 radiance0(CTX &ctx, const TraceParams &p, const TriShade *triShade,
+                                        const SphereRec *spheres, d3 o, d3 d) {
+  if (p.maxDepth <= 0) return mk(0, 0, 0);
+  const HitKey k = ctx.intersect(o, d);
+  if (ctx.branch(k.idx == kMiss)) return ld3(p.env);
+  const Surface s = makeSurface(p, triShade, spheres, k, o, d);
+  if (p.preview) return s.diffuse; // Scene.cpp:137-138
+  d3 result = mk(0, 0, 0);
+  for (int uS = 0; uS < p.fbU; ++uS) {
+    for (int vS = 0; vS < p.fbV; ++vS) {
+      // (double(uSample) + unit(rng)) / double(numUSamples): a power-of-two divisor is an exact
+      // scaling, so multiply by its reciprocal; otherwise divide.
+      const double ur = static_cast<double>(uS) + ctx.draw();
+      const double u = p.uPow2 ? ur * p.invU : ur / static_cast<double>(p.fbU);
+      const double vr = static_cast<double>(vS) + ctx.draw();
+      const double v = p.vPow2 ? vr * p.invV : vr / static_cast<double>(p.fbV);
+      const double pd = ctx.draw();
+      d3 nd;
+      const bool refl = scatter(ctx, s, d, u, v, pd, nd);
+      const d3 child = radianceChain(ctx, p, triShade, spheres, s.pos, nd);
+      result = result + (refl ? s.emission + child : s.emission + s.diffuse * child);
+    }
+  }
+  return result * p.invFirstBounce; // Vec3::operator/(double): multiply by 1.0 / (nU * nV)
+}
+
+// -----------------------------------------------------------------------------------------
+// SEQUENTIAL policy context: one workgroup (WAVES x 64 lanes) per pass.
+// -----------------------------------------------------------------------------------------
+struct SeqShared {
+  uint32_t mt[kMtWords];
+  double canon[kMtDoubles];
+};
+
+struct PartialHit {
+  double t;
+  double det;
+  uint32_t idx;
+  uint32_t pad;
+};
+
+// std::mt19937 regeneration (the "twist") + tempering + generate_canonical for all 312
+// doubles, by the 64 lanes of one wave.  Chunks of 64 consecutive k are processed in order;
+// inside a chunk every lane reads its inputs before any lane writes (one wave = lockstep).
+// Kept out of line: it runs once per 312 draws and would otherwise be cloned into every
+// draw() site.
+__device__ __noinline__ void mtRegenerateWave(SeqShared *sh, int lane) {
+  uint32_t *x = sh->mt;
+  for (int base = 0; base < 227; base += 64) { // k in [0, 227): far = old x[k + 397]
+    const int k = base + lane;
+    uint32_t nv = 0;
+    if (k < 227) nv = mtTwist(x[k], x[k + 1], x[k + 397]);
+    if (k < 227) x[k] = nv;
+  }
+  for (int base = 227; base < 623; base += 64) { // k in [227, 623): far = new x[k - 227]
+    const int k = base + lane;
+    uint32_t nv = 0;
+    if (k < 623) nv = mtTwist(x[k], x[k + 1], x[k - 227]);
+    if (k < 623) x[k] = nv;
+  }
+  if (lane == 0) x[623] = mtTwist(x[623], x[0], x[396]);
+  for (int i = lane; i < kMtDoubles; i += 64)
+    sh->canon[i] = canonicalFromWords(mtTemper(x[2 * i]), mtTemper(x[2 * i + 1]));
+}
+
+template <int SLOTS, int WAVES>
+struct SeqCtx {
+  static constexpr int kThreads = 64 * WAVES;
+
+  // per-lane resident triangles (SoA in registers)
+  double v0x[SLOTS], v0y[SLOTS], v0z[SLOTS];
+  double e1x[SLOTS], e1y[SLOTS], e1z[SLOTS];
+  double e2x[SLOTS], e2y[SLOTS], e2z[SLOTS];
+  // per-lane resident sphere (lane tid owns sphere tid when tid < nsph)
+  double scx, scy, scz, sr2;
+  bool hasSphere;
+
+  const TraceParams *p;
+  const double *triGeom;
+  const SphereRec *spheres;
+  SeqShared *sh;
+  Level *stack;          // this wave's private radiance stack in LDS
+  PartialHit *partials;  // [2][WAVES] cross-wave exchange (WAVES > 1)
+  int tid;
+  int pos;               // next canonical double in sh->canon (wave-uniform)
+  unsigned words;        // RNG words consumed by the current sample
+  unsigned long long rays;
+  unsigned parity;
+
+  __device__ __forceinline__ bool branch(bool b) const { return uniformBool(b); }
+
+  __device__ __forceinline__ void loadPrimitives() {
+    const uint32_t ntri = p->ntri;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const uint32_t k = static_cast<uint32_t>(tid) * SLOTS + s;
+      if (k < ntri) {
+        const double *g = triGeom + 9 * static_cast<size_t>(k);
+        v0x[s] = g[0], v0y[s] = g[1], v0z[s] = g[2];
+        e1x[s] = g[3], e1y[s] = g[4], e1z[s] = g[5];
+        e2x[s] = g[6], e2y[s] = g[7], e2z[s] = g[8];
+      } else { // degenerate: det == 0 -> always skipped
+        v0x[s] = v0y[s] = v0z[s] = 0;
+        e1x[s] = e1y[s] = e1z[s] = 0;
+        e2x[s] = e2y[s] = e2z[s] = 0;
+      }
+    }
+    hasSphere = static_cast<uint32_t>(tid) < p->nsph;
+    if (hasSphere) {
+      const SphereRec &r = spheres[tid];
+      scx = r.centre[0], scy = r.centre[1], scz = r.centre[2], sr2 = r.radiusSquared;
+    } else {
+      scx = scy = scz = sr2 = 0;
+    }
+  }
+
+  __device__ __forceinline__ void regenerate() {
+    if (WAVES > 1) __syncthreads();
+    if (tid < 64) mtRegenerateWave(sh, tid);
+    if (WAVES > 1) __syncthreads();
+  }
+
+  // Rebuild canon[] from the current raw state without twisting (state resumed mid-block).
+  __device__ __forceinline__ void rebuildCanon() {
+    if (tid < 64)
+      for (int i = tid; i < kMtDoubles; i += 64)
+        sh->canon[i] = canonicalFromWords(mtTemper(sh->mt[2 * i]), mtTemper(sh->mt[2 * i + 1]));
+    if (WAVES > 1) __syncthreads();
+  }
+
+  __device__ __forceinline__ double draw() {
+    if (pos == kMtDoubles) {
+      regenerate();
+      pos = 0;
+    }
+    words += 2;
+    return sh->canon[pos++];
+  }
+
+  __device__ __forceinline__ void push(int level, d3 e, d3 dif, bool refl) {
+    if ((tid & 63) == 0) { // one lane writes; every lane of the wave reads it back
+      Level lv;
+      lv.emission = e;
+      lv.diffuse = dif;
+      lv.reflective = refl;
+      stack[level] = lv;
+    }
+  }
+  __device__ __forceinline__ Level top(int level) const { return stack[level]; }
+
+  // Scene::intersect, Scene.cpp:115-122, cooperatively.
+  __device__ __forceinline__ HitKey intersect(d3 o, d3 d) {
+    rays++;
+    double bestT = kInf, bestDet = 0;
+    uint32_t bestIdx = kMiss;
+    const uint32_t nsph = p->nsph;
+    // spheres first (lower combined index)
+    if (hasSphere) testSphere(o, d, mk(scx, scy, scz), sr2, static_cast<uint32_t>(tid), bestT, bestIdx);
+    for (uint32_t i = tid + kThreads; i < nsph; i += kThreads) { // rare: > 64*WAVES spheres
+      const SphereRec &r = spheres[i];
+      testSphere(o, d, ld3(r.centre), r.radiusSquared, i, bestT, bestIdx);
+    }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s)
+      testTriangle(o, d, mk(v0x[s], v0y[s], v0z[s]), mk(e1x[s], e1y[s], e1z[s]),
+                   mk(e2x[s], e2y[s], e2z[s]), nsph + static_cast<uint32_t>(tid) * SLOTS + s,
+                   bestT, bestIdx, bestDet);
+    // rare: more triangles than resident slots -> stream the remainder from memory
+    for (uint32_t k = static_cast<uint32_t>(kThreads) * SLOTS + tid; k < p->ntri; k += kThreads) {
+      const double *g = triGeom + 9 * static_cast<size_t>(k);
+      testTriangle(o, d, ld3(g), ld3(g + 3), ld3(g + 6), nsph + k, bestT, bestIdx, bestDet);
+    }
+
+    // wave reduction: lexicographic min of (t, idx)
+    const double tmin = waveMin(bestT);
+    HitKey key;
+    if (tmin == kInf) {
+      key.t = kInf, key.idx = kMiss, key.det = 0;
+    } else {
+      const uint32_t cand = bestT == tmin ? bestIdx : kMiss;
+      const uint32_t imin = waveMinU(cand);
+      const unsigned long long owner = __builtin_amdgcn_ballot_w64(bestIdx == imin);
+      const int lane = __builtin_ctzll(owner);
+      key.t = tmin;
+      key.idx = imin;
+      key.det = readLane(bestDet, lane);
+    }
+    if (WAVES > 1) {
+      PartialHit *slot = partials + (parity & 1u) * WAVES;
+      parity++;
+      if ((tid & 63) == 0) {
+        PartialHit ph;
+        ph.t = key.t, ph.det = key.det, ph.idx = key.idx, ph.pad = 0;
+        slot[tid >> 6] = ph;
+      }
+      __syncthreads();
+      HitKey best;
+      best.t = kInf, best.idx = kMiss, best.det = 0;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) {
+        const PartialHit ph = slot[w];
+        if (ph.t < best.t || (ph.t == best.t && ph.idx < best.idx)) {
+          best.t = ph.t, best.idx = ph.idx, best.det = ph.det;
+        }
+      }
+      key.t = readFirstLane(best.t);
+      key.det = readFirstLane(best.det);
+      key.idx = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(best.idx)));
+    }
+    return key;
+  }
+};
+
+template <int SLOTS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void traceSequential(
+    const TraceParams p, const double *__restrict__ triGeom,
+    const TriShade *__restrict__ triShade, const SphereRec *__restrict__ spheres,
+    uint32_t *__restrict__ mtState, uint32_t *__restrict__ mtPos, double *__restrict__ stage,
+    uint32_t *__restrict__ words, unsigned long long *__restrict__ rayCounters) {
+  __shared__ SeqShared sh;
+  __shared__ Level stacks[WAVES][kMaxDepth];
+  __shared__ PartialHit partials[2 * WAVES];
+
+  const int pass = blockIdx.x;
+  SeqCtx<SLOTS, WAVES> ctx;
+  ctx.p = &p;
+  ctx.triGeom = triGeom;
+  ctx.spheres = spheres;
+  ctx.sh = &sh;
+  ctx.tid = threadIdx.x;
+  ctx.stack = stacks[threadIdx.x >> 6];
+  ctx.partials = partials;
+  ctx.words = 0;
+  ctx.rays = 0;
+  ctx.parity = 0;
+  ctx.loadPrimitives();
+
+  // resume this pass's generator
+  uint32_t *myState = mtState + static_cast<size_t>(pass) * kMtWords;
+  for (int i = threadIdx.x; i < kMtWords; i += 64 * WAVES) sh.mt[i] = myState[i];
+  ctx.pos = __builtin_amdgcn_readfirstlane(static_cast<int>(mtPos[pass]));
+  __syncthreads();
+  if (ctx.pos < kMtDoubles) ctx.rebuildCanon();
+
+  const int w = p.width;
+  const bool lens = p.cam.aperture_radius != 0;
+  double *myStage = stage + static_cast<size_t>(pass) * p.pixCount * 3;
+  for (uint32_t i = 0; i < p.pixCount; ++i) {
+    const uint32_t pix = p.pixBegin + i;
+    const int px = static_cast<int>(pix % static_cast<uint32_t>(w));
+    const int py = static_cast<int>(pix / static_cast<uint32_t>(w));
+    ctx.words = 0;
+    const double r0 = ctx.draw();
+    const double r1 = ctx.draw();
+    double r2 = 0, r3 = 0;
+    if (lens) {
+      r2 = ctx.draw();
+      r3 = ctx.draw();
+    }
+    d3 o, d;
+    cameraRay(p.cam, px, py, r0, r1, r2, r3, o, d);
+    const d3 L = radiance0(ctx, p, triShade, spheres, o, d);
+    if (threadIdx.x == 0) {
+      myStage[i * 3 + 0] = L.x;
+      myStage[i * 3 + 1] = L.y;
+      myStage[i * 3 + 2] = L.z;
+      if (words) words[static_cast<size_t>(pass) * p.npix + pix] = ctx.words;
+    }
+  }
+
+  // park the generator for the next band
+  __syncthreads();
+  for (int i = threadIdx.x; i < kMtWords; i += 64 * WAVES) myState[i] = sh.mt[i];
+  if (threadIdx.x == 0) {
+    mtPos[pass] = static_cast<uint32_t>(ctx.pos);
+    if (rayCounters) rayCounters[pass] += ctx.rays;
+  }
+}
+
+// -----------------------------------------------------------------------------------------
+// PERPIXEL policy: one lane per (pass, pixel) sample; primitives streamed from memory with
+// wave-uniform addresses (every lane of a wave tests the same triangle).
+// -----------------------------------------------------------------------------------------
+struct PixCtx {
+  const TraceParams *p;
+  const double *triGeom;
+  const SphereRec *spheres;
+  Sfc32 rng;
+  unsigned words;
+  unsigned long long rays;
+  Level *stack; // this lane's slice of the block's LDS stack, stride = blockDim.x
+
+  __device__ __forceinline__ bool branch(bool b) const { return b; }
+  __device__ __forceinline__ double draw() {
+    const uint32_t w0 = rng.next();
+    const uint32_t w1 = rng.next();
+    words += 2;
+    return canonicalFromWords(w0, w1);
+  }
+  __device__ __forceinline__ void push(int level, d3 e, d3 dif, bool refl) {
+    Level lv;
+    lv.emission = e;
+    lv.diffuse = dif;
+    lv.reflective = refl;
+    stack[level * blockDim.x] = lv;
+  }
+  __device__ __forceinline__ Level top(int level) const { return stack[level * blockDim.x]; }
+
+  __device__ __forceinline__ HitKey intersect(d3 o, d3 d) {
+    rays++;
+    HitKey key;
+    key.t = kInf, key.idx = kMiss, key.det = 0;
+    const uint32_t nsph = p->nsph, ntri = p->ntri;
+    for (uint32_t i = 0; i < nsph; ++i) {
+      const SphereRec &r = spheres[i];
+      testSphere(o, d, ld3(r.centre), r.radiusSquared, i, key.t, key.idx);
+    }
+    for (uint32_t k = 0; k < ntri; ++k) {
+      const double *g = triGeom + 9 * static_cast<size_t>(k);
+      testTriangle(o, d, ld3(g), ld3(g + 3), ld3(g + 6), nsph + k, key.t, key.idx, key.det);
+    }
+    return key;
+  }
+};
+
+constexpr int kPixBlock = 256;
+
+__global__ __launch_bounds__(kPixBlock) void tracePerPixel(
+    const TraceParams p, const double *__restrict__ triGeom,
+    const TriShade *__restrict__ triShade, const SphereRec *__restrict__ spheres,
+    double *__restrict__ stage, uint32_t *__restrict__ words,
+    unsigned long long *__restrict__ rayCounters) {
+  extern __shared__ Level pixStacks[]; // [maxDepth][blockDim.x]
+  const uint64_t gid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
+  if (gid >= total) return;
+  // consecutive lanes = consecutive pixels of one pass (coalesced stage writes)
+  const uint32_t pass = static_cast<uint32_t>(gid / p.pixCount);
+  const uint32_t i = static_cast<uint32_t>(gid % p.pixCount);
+  const uint32_t pix = p.pixBegin + i;
+
+  PixCtx ctx;
+  ctx.p = &p;
+  ctx.triGeom = triGeom;
+  ctx.spheres = spheres;
+  ctx.words = 0;
+  ctx.rays = 0;
+  ctx.stack = pixStacks + threadIdx.x;
+  ctx.rng.seed(p.passSeedBase + pass, pix);
+
+  const int px = static_cast<int>(pix % static_cast<uint32_t>(p.width));
+  const int py = static_cast<int>(pix / static_cast<uint32_t>(p.width));
+  const double r0 = ctx.draw();
+  const double r1 = ctx.draw();
+  double r2 = 0, r3 = 0;
+  if (p.cam.aperture_radius != 0) {
+    r2 = ctx.draw();
+    r3 = ctx.draw();
+  }
+  d3 o, d;
+  cameraRay(p.cam, px, py, r0, r1, r2, r3, o, d);
+  const d3 L = radiance0(ctx, p, triShade, spheres, o, d);
+  double *out = stage + (static_cast<size_t>(pass) * p.pixCount + i) * 3;
+  out[0] = L.x, out[1] = L.y, out[2] = L.z;
+  if (words) words[static_cast<size_t>(pass) * p.npix + pix] = ctx.words;
+  if (rayCounters) atomicAdd(&rayCounters[pass], ctx.rays);
+}
+
+// -----------------------------------------------------------------------------------------
+// resolve: pass-ordered accumulation into the ArrayOutput-shaped running sums.
+// -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resolveKernel(const double *__restrict__ stage,
+                                                     uint32_t npass, uint32_t pixBegin,
+                                                     uint32_t pixCount, double *__restrict__ rgbSum,
+                                                     uint32_t *__restrict__ counts) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; // element = pixel * 3 + channel
+  const uint32_t n = pixCount * 3;
+  if (e >= n) return;
+  const size_t base = static_cast<size_t>(pixBegin) * 3 + e;
+  double acc = rgbSum[base];
+  for (uint32_t k = 0; k < npass; ++k) acc += stage[static_cast<size_t>(k) * n + e];
+  rgbSum[base] = acc;
+  if (e < pixCount) counts[pixBegin + e] += npass;
+}
+
+// -----------------------------------------------------------------------------------------
+// Batch Scene::intersect for known-answer tests: one lane per ray.
+// -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void intersectBatchKernel(
+    const TraceParams p, const double *__restrict__ triGeom,
+    const TriShade *__restrict__ triShade, const SphereRec *__restrict__ spheres,
+    const double *__restrict__ rays, uint64_t n, double *__restrict__ hits) {
+  const uint64_t gid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (gid >= n) return;
+  PixCtx ctx;
+  ctx.p = &p;
+  ctx.triGeom = triGeom;
+  ctx.spheres = spheres;
+  ctx.rays = 0;
+  const d3 o = ld3(rays + gid * 6), d = ld3(rays + gid * 6 + 3);
+  const HitKey k = ctx.intersect(o, d);
+  double *h = hits + gid * 9;
+  if (k.idx == kMiss) {
+    h[0] = -1;
+    for (int i = 1; i < 9; ++i) h[i] = 0;
+    return;
+  }
+  const d3 pos = o + d * k.t;
+  d3 n3;
+  bool inside;
+  if (k.idx >= p.nsph) {
+    const TriShade &r = triShade[k.idx - p.nsph];
+    inside = k.det < kEpsilon;
+    n3 = inside ? -ld3(r.normal) : ld3(r.normal);
+  } else {
+    n3 = normalised(pos - ld3(spheres[k.idx].centre));
+    inside = dot(n3, d) > 0;
+    if (inside) n3 = -n3;
+  }
+  h[0] = k.t;
+  h[1] = inside ? 1.0 : 0.0;
+  h[2] = pos.x, h[3] = pos.y, h[4] = pos.z;
+  h[5] = n3.x, h[6] = n3.y, h[7] = n3.z;
+  h[8] = static_cast<double>(k.idx); // combined primitive index; the host maps it to a material
+}
+
+template <int SLOTS, int WAVES>
+hipError_t launchSeq(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
+  hipLaunchKernelGGL((traceSequential<SLOTS, WAVES>), dim3(p.npass), dim3(64 * WAVES), 0, stream,
+                     p, b.triGeom, b.triShade, b.spheres, b.mtState, b.mtPos, b.stage, b.words,
+                     b.rays);
+  return hipGetLastError();
+}
+
+} // namespace
+
+hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
+  const uint32_t n = p.ntri;
+  // Smallest resident configuration that holds every triangle in VGPRs; 1 wave up to 128
+  // triangles, otherwise 4 waves (one per SIMD of a CU) with up to 16 slots per lane.
+  if (n <= 64) return launchSeq<1, 1>(p, b, stream);
+  if (n <= 128) return launchSeq<2, 1>(p, b, stream);
+  if (n <= 256) return launchSeq<1, 4>(p, b, stream);
+  if (n <= 512) return launchSeq<2, 4>(p, b, stream);
+  if (n <= 1024) return launchSeq<4, 4>(p, b, stream);
+  if (n <= 2048) return launchSeq<8, 4>(p, b, stream);
+  return launchSeq<16, 4>(p, b, stream); // beyond 4096 the tail is streamed from memory
+}
+
+hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
+  const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
+  const uint32_t blocks = static_cast<uint32_t>((total + kPixBlock - 1) / kPixBlock);
+  const int levels = p.maxDepth > 1 ? p.maxDepth - 1 : 1;
+  const size_t lds = static_cast<size_t>(levels) * kPixBlock * sizeof(Level);
+  hipLaunchKernelGGL(tracePerPixel, dim3(blocks), dim3(kPixBlock), lds, stream, p, b.triGeom,
+                     b.triShade, b.spheres, b.stage, b.words, b.rays);
+  return hipGetLastError();
+}
+
+hipError_t launchResolve(const double *stage, uint32_t npass, uint32_t pixBegin, uint32_t pixCount,
+                         double *rgbSum, uint32_t *counts, hipStream_t stream) {
+  const uint32_t n = pixCount * 3;
+  hipLaunchKernelGGL(resolveKernel, dim3((n + 255) / 256), dim3(256), 0, stream, stage, npass,
+                     pixBegin, pixCount, rgbSum, counts);
+  return hipGetLastError();
+}
+
+hipError_t launchIntersectBatch(const TraceParams &p, const TraceBuffers &b, const double *rays,
+                                uint64_t n, double *hitsOut, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(intersectBatchKernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256),
+                     0, stream, p, b.triGeom, b.triShade, b.spheres, rays, n, hitsOut);
+  return hipGetLastError();
+}
+
+} // namespace ptw

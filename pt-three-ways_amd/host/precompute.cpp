@@ -1,0 +1,86 @@
+#include "precompute.h"
+#include "vec3.h"
+
+#include <cstring>
+#include <stdexcept>
+
+namespace ptw {
+namespace {
+
+void copyMaterial(const ptw_material &m, double emission[3], double diffuse[3], double &ior,
+                  double &invIor, double &reflectivity, double &cone) {
+  std::memcpy(emission, m.emission, sizeof m.emission);
+  std::memcpy(diffuse, m.diffuse, sizeof m.diffuse);
+  ior = m.index_of_refraction;
+  invIor = 1.0 / m.index_of_refraction; // iorFrom / iorTo for an outside hit, Norm3.cpp:11
+  reflectivity = m.reflectivity;
+  cone = m.reflection_cone_angle_rad;
+}
+
+} // namespace
+
+DeviceSceneData precomputeScene(const ptw_scene_view &scene) {
+  DeviceSceneData out;
+  std::memcpy(out.environment, scene.environment, sizeof out.environment);
+  out.triGeom.resize(static_cast<size_t>(scene.num_triangles) * 9);
+  out.triShade.resize(scene.num_triangles);
+  out.spheres.resize(scene.num_spheres);
+  out.triMaterial.assign(scene.tri_material, scene.tri_material + scene.num_triangles);
+  out.sphMaterial.assign(scene.sph_material, scene.sph_material + scene.num_spheres);
+
+  for (uint32_t i = 0; i < scene.num_triangles; ++i) {
+    const double *tv = scene.tri_vertices + 9 * static_cast<size_t>(i);
+    const Vec3d v0(tv), v1(tv + 3), v2(tv + 6);
+    const Vec3d e1 = v1 - v0; // TriangleVertices::uVector, TriangleVertices.h:25-27
+    const Vec3d e2 = v2 - v0; // TriangleVertices::vVector, :29-31
+    double *g = &out.triGeom[9 * static_cast<size_t>(i)];
+    v0.store(g), e1.store(g + 3), e2.store(g + 6);
+
+    // faceNormal() stored three times (Scene.cpp:183-185); intersectTriangles then forms
+    // (u * (n1 - n0) + v * (n2 - n0) + n0).normalised() (Scene.cpp:100-106).  With n0 == n1 ==
+    // n2 the deltas are exactly zero and u, v are finite, so the sum is n0 for every hit.
+    const Vec3d face = normalised(cross(e1, e2));
+    const Vec3d zero = face - face;
+    const Vec3d blended = (0.5 * zero + 0.5 * zero) + face;
+    const Vec3d normal = normalised(blended);
+
+    // OrthoNormalBasis::fromZ(normal), OrthoNormalBasis.cpp:44-51
+    const double zDotX = normal.x * 1.0 + normal.y * 0.0 + normal.z * 0.0;
+    const Vec3d a = std::fabs(zDotX) > 0.9999 ? Vec3d(0, 1, 0) : Vec3d(1, 0, 0);
+    const Vec3d bx = normalised(cross(a, normal));
+    const Vec3d by = normalised(cross(normal, bx));
+
+    TriShade &r = out.triShade[i];
+    std::memset(&r, 0, sizeof r);
+    normal.store(r.normal);
+    bx.store(r.basisX);
+    by.store(r.basisY);
+    if (scene.tri_material[i] >= scene.num_materials)
+      throw std::runtime_error("triangle material index out of range");
+    copyMaterial(scene.materials[scene.tri_material[i]], r.emission, r.diffuse, r.ior, r.invIor,
+                 r.reflectivity, r.coneAngle);
+  }
+
+  for (uint32_t i = 0; i < scene.num_spheres; ++i) {
+    const double *sp = scene.sph_centre_radius + 4 * static_cast<size_t>(i);
+    SphereRec &r = out.spheres[i];
+    std::memset(&r, 0, sizeof r);
+    r.centre[0] = sp[0], r.centre[1] = sp[1], r.centre[2] = sp[2];
+    r.radiusSquared = sp[3] * sp[3]; // dod::Sphere ctor, Sphere.h:11-12
+    if (scene.sph_material[i] >= scene.num_materials)
+      throw std::runtime_error("sphere material index out of range");
+    copyMaterial(scene.materials[scene.sph_material[i]], r.emission, r.diffuse, r.ior, r.invIor,
+                 r.reflectivity, r.coneAngle);
+  }
+  return out;
+}
+
+void seedMt19937(uint32_t seed, uint32_t state[624]) {
+  state[0] = seed;
+  for (uint32_t i = 1; i < 624; ++i) {
+    const uint32_t prev = state[i - 1];
+    state[i] = 1812433253u * (prev ^ (prev >> 30)) + i;
+  }
+}
+
+} // namespace ptw
