@@ -199,6 +199,13 @@ int ptw_context_get_stats(ptw_context *ctx, ptw_kernel_stats *out, int32_t reset
  * for a miss), inside flag, position, normal, material index (as doubles: 9 per ray). */
 int ptw_context_intersect(ptw_context *ctx, const double *rays, uint64_t n, double *hits_out);
 
+/* Known-answer hook for the device RNG: the first n values a
+ * std::uniform_real_distribution<double>(0,1) draws from std::mt19937(seed) (SEQUENTIAL,
+ * src/dod/Scene.cpp:149,211) or from the PERPIXEL stream of (pass_seed = seed, pixel), produced
+ * by the same device code the render kernels use. */
+int ptw_context_rng_doubles(ptw_context *ctx, int32_t rng_policy, uint32_t seed, uint32_t pixel,
+                            uint32_t n, double *out);
+
 /* ---- ArrayOutput surface, src/util/ArrayOutput.cpp ------------------------------------- */
 /* .raw: header {u32 signature=1, version=1, height, width} then per pixel 3 x f64 sum +
  * u32 count (ArrayOutput.cpp:21-28,65-81). */

@@ -45,6 +45,17 @@ if not LIB_PATH.exists():
         f"{LIB_PATH} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
         "(or `make -C pt-three-ways_amd`). The hip way has no CPU fallback.")
 
+# One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.  When torch is
+# going to be used in this process (device buffers, streams, torch.distributed/RCCL) it must be
+# loaded FIRST so that libptw_hip.so's NEEDED libamdhip64.so.7 binds to the same runtime;
+# two runtimes in one process leave the second one without devices.  PTW_NO_TORCH=1 skips this
+# (pure C-ABI use, e.g. a host that is not Python).
+if os.environ.get("PTW_NO_TORCH", "0") != "1":
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
 lib = C.CDLL(str(LIB_PATH))
 
 
@@ -140,6 +151,8 @@ _sig("ptw_context_render", C.c_int, C.c_void_p, C.POINTER(Camera), C.POINTER(Ren
 _sig("ptw_context_enable_stats", C.c_int, C.c_void_p, C.c_int32)
 _sig("ptw_context_get_stats", C.c_int, C.c_void_p, C.POINTER(KernelStats), C.c_int32)
 _sig("ptw_context_intersect", C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+_sig("ptw_context_rng_doubles", C.c_int, C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32,
+     C.c_void_p)
 _sig("ptw_raw_save", C.c_int, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p)
 _sig("ptw_raw_read_header", C.c_int, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32))
 _sig("ptw_raw_load_accumulate", C.c_int, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p,
@@ -318,6 +331,11 @@ class Context:
         s = KernelStats()
         _check(lib.ptw_context_get_stats(self._h, C.byref(s), int(bool(reset))))
         return s
+
+    def rng_doubles(self, policy: int, seed: int, n: int, pixel: int = 0) -> np.ndarray:
+        out = np.zeros(n, dtype=np.float64)
+        _check(lib.ptw_context_rng_doubles(self._h, policy, seed, pixel, n, out.ctypes.data))
+        return out
 
     def intersect(self, rays: np.ndarray) -> np.ndarray:
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)

@@ -373,6 +373,24 @@ int ptw_context_intersect(ptw_context *ctx, const double *rays, uint64_t n, doub
   PTW_GUARD_END
 }
 
+int ptw_context_rng_doubles(ptw_context *ctx, int32_t rng_policy, uint32_t seed, uint32_t pixel,
+                            uint32_t n, double *out) {
+  if (!ctx || (!out && n)) return invalid("null pointer");
+  PTW_GUARD_BEGIN
+  ctx->activate();
+  if (n == 0) return PTW_OK;
+  uint32_t state[kMtWords];
+  seedMt19937(seed, state);
+  DeviceArray<uint32_t> dState;
+  DeviceArray<double> dOut;
+  dState.upload(state, kMtWords, nullptr);
+  dOut.reserve(n);
+  check(launchRngKat(rng_policy, dState.ptr, seed, pixel, n, dOut.ptr, nullptr), "rng kat launch");
+  check(hipMemcpy(out, dOut.ptr, n * sizeof(double), hipMemcpyDeviceToHost), "D2H");
+  return PTW_OK;
+  PTW_GUARD_END
+}
+
 int ptw_render(const ptw_scene_view *scene, const ptw_camera *camera,
                const ptw_render_params *params, double *rgb_sum, uint32_t *counts,
                ptw_progress_fn progress, void *user) {

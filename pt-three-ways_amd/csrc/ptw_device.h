@@ -115,6 +115,16 @@ __device__ __forceinline__ bool uniformBool(bool b) {
   return __builtin_amdgcn_readfirstlane(static_cast<int>(b)) != 0;
 }
 
+// Orders this wave's LDS/global accesses for cross-LANE communication through memory.  The
+// lanes of a wave execute in lockstep, but the compiler only sees one thread: without a fence
+// it may hoist a later load above an earlier store to an address that (for this thread) does
+// not alias, which breaks data another lane wrote.  No instruction is emitted beyond waits.
+__device__ __forceinline__ void waveSync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int Ctrl, int RowMask>
 __device__ __forceinline__ double dppMove(double x) {
   // lanes the DPP pattern does not feed keep their own value (old = x, bound_ctrl = 0)

@@ -49,4 +49,8 @@ hipError_t launchResolve(const double *stage, uint32_t npass, uint32_t pixBegin,
 hipError_t launchIntersectBatch(const TraceParams &p, const TraceBuffers &b, const double *rays,
                                 uint64_t n, double *hitsOut, hipStream_t stream);
 
+// Device RNG known-answer test: n canonical doubles from mt19937(state) / the sfc32 stream.
+hipError_t launchRngKat(int rngPolicy, const uint32_t *mtSeedState, uint32_t seed, uint32_t pixel,
+                        uint32_t n, double *out, hipStream_t stream);
+
 } // namespace ptw

@@ -268,26 +268,34 @@ struct PartialHit {
 
 // std::mt19937 regeneration (the "twist") + tempering + generate_canonical for all 312
 // doubles, by the 64 lanes of one wave.  Chunks of 64 consecutive k are processed in order;
-// inside a chunk every lane reads its inputs before any lane writes (one wave = lockstep).
+// inside a chunk every lane reads its inputs, waveSync(), then writes, waveSync() - the
+// fences keep the compiler from reordering one lane's loads across another lane's stores.
 // Kept out of line: it runs once per 312 draws and would otherwise be cloned into every
 // draw() site.
 __device__ __noinline__ void mtRegenerateWave(SeqShared *sh, int lane) {
   uint32_t *x = sh->mt;
+  waveSync();
   for (int base = 0; base < 227; base += 64) { // k in [0, 227): far = old x[k + 397]
     const int k = base + lane;
     uint32_t nv = 0;
     if (k < 227) nv = mtTwist(x[k], x[k + 1], x[k + 397]);
+    waveSync();
     if (k < 227) x[k] = nv;
+    waveSync();
   }
   for (int base = 227; base < 623; base += 64) { // k in [227, 623): far = new x[k - 227]
     const int k = base + lane;
     uint32_t nv = 0;
     if (k < 623) nv = mtTwist(x[k], x[k + 1], x[k - 227]);
+    waveSync();
     if (k < 623) x[k] = nv;
+    waveSync();
   }
   if (lane == 0) x[623] = mtTwist(x[623], x[0], x[396]);
+  waveSync();
   for (int i = lane; i < kMtDoubles; i += 64)
     sh->canon[i] = canonicalFromWords(mtTemper(x[2 * i]), mtTemper(x[2 * i + 1]));
+  waveSync();
 }
 
 template <int SLOTS, int WAVES>
@@ -352,7 +360,7 @@ struct SeqCtx {
     if (tid < 64)
       for (int i = tid; i < kMtDoubles; i += 64)
         sh->canon[i] = canonicalFromWords(mtTemper(sh->mt[2 * i]), mtTemper(sh->mt[2 * i + 1]));
-    if (WAVES > 1) __syncthreads();
+    __syncthreads();
   }
 
   __device__ __forceinline__ double draw() {
@@ -365,13 +373,12 @@ struct SeqCtx {
   }
 
   __device__ __forceinline__ void push(int level, d3 e, d3 dif, bool refl) {
-    if ((tid & 63) == 0) { // one lane writes; every lane of the wave reads it back
-      Level lv;
-      lv.emission = e;
-      lv.diffuse = dif;
-      lv.reflective = refl;
-      stack[level] = lv;
-    }
+    // every lane stores the same (wave-uniform) value, so each lane reads back its own write
+    Level lv;
+    lv.emission = e;
+    lv.diffuse = dif;
+    lv.reflective = refl;
+    stack[level] = lv;
   }
   __device__ __forceinline__ Level top(int level) const { return stack[level]; }
 
@@ -651,6 +658,34 @@ __global__ __launch_bounds__(256) void intersectBatchKernel(
   h[8] = static_cast<double>(k.idx); // combined primitive index; the host maps it to a material
 }
 
+// Device RNG known-answer kernel: one wave drives the same LDS generator the render uses.
+__global__ __launch_bounds__(64) void rngKatKernel(int rngPolicy,
+                                                   const uint32_t *__restrict__ seedState,
+                                                   uint32_t seed, uint32_t pixel, uint32_t n,
+                                                   double *__restrict__ out) {
+  __shared__ SeqShared sh;
+  if (rngPolicy == PTW_RNG_SEQUENTIAL) {
+    for (int i = threadIdx.x; i < kMtWords; i += 64) sh.mt[i] = seedState[i];
+    int pos = kMtDoubles;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (pos == kMtDoubles) {
+        mtRegenerateWave(&sh, threadIdx.x);
+        pos = 0;
+      }
+      const double v = sh.canon[pos++];
+      if (threadIdx.x == 0) out[i] = v;
+    }
+  } else if (threadIdx.x == 0) {
+    Sfc32 rng;
+    rng.seed(seed, pixel);
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint32_t w0 = rng.next();
+      const uint32_t w1 = rng.next();
+      out[i] = canonicalFromWords(w0, w1);
+    }
+  }
+}
+
 template <int SLOTS, int WAVES>
 hipError_t launchSeq(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
   hipLaunchKernelGGL((traceSequential<SLOTS, WAVES>), dim3(p.npass), dim3(64 * WAVES), 0, stream,
@@ -689,6 +724,13 @@ hipError_t launchResolve(const double *stage, uint32_t npass, uint32_t pixBegin,
   const uint32_t n = pixCount * 3;
   hipLaunchKernelGGL(resolveKernel, dim3((n + 255) / 256), dim3(256), 0, stream, stage, npass,
                      pixBegin, pixCount, rgbSum, counts);
+  return hipGetLastError();
+}
+
+hipError_t launchRngKat(int rngPolicy, const uint32_t *mtSeedState, uint32_t seed, uint32_t pixel,
+                        uint32_t n, double *out, hipStream_t stream) {
+  hipLaunchKernelGGL(rngKatKernel, dim3(1), dim3(64), 0, stream, rngPolicy, mtSeedState, seed,
+                     pixel, n, out);
   return hipGetLastError();
 }
 

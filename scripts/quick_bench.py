@@ -1,0 +1,20 @@
+import sys, time
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import numpy as np, torch
+import __graft_entry__ as e
+pkg = e.load_package()
+def run(name, w, h, spp, policy):
+    scene = pkg.Scene(); cam = scene.build_named(name, w, h)
+    ctx = pkg.Context(0); ctx.set_scene(scene); ctx.enable_stats(True)
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=1, rng_policy=policy)
+    rgb = torch.zeros((h, w, 3), dtype=torch.float64, device='cuda'); cnt = torch.zeros((h, w), dtype=torch.int32, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize(); t = time.time()
+    ctx.render(cam, params, rgb.data_ptr(), cnt.data_ptr(), 0, st)
+    torch.cuda.synchronize(); dt = time.time() - t
+    s = ctx.stats(True)
+    n = w * h * spp
+    print(f"{name} {w}x{h}x{spp} policy={policy}: {dt:.3f}s  {n/dt/1e6:.3f} Msamples/s  trace_ms={s.trace_ms:.1f} ({s.trace_launches} launches) resolve_ms={s.resolve_ms:.2f} rays/sample={s.rays/max(1,s.samples):.2f} mean={rgb.mean().item()/spp:.6f}", flush=True)
+for a in sys.argv[1:]:
+    name, w, h, spp, pol = a.split(',')
+    run(name, int(w), int(h), int(spp), int(pol))
