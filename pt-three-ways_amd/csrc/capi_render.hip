@@ -8,6 +8,7 @@
 #include "../host/precompute.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <utility>
@@ -262,6 +263,16 @@ int ptw_context_create(int32_t device, ptw_context **out) {
     throw DeviceError(PTW_ERR_NO_DEVICE, "HIP device ordinal out of range");
   auto ctx = std::make_unique<ptw_context>();
   ctx->device = device;
+  // Staging budget override (MiB); small values force many bands - used by the tests to prove
+  // the result does not depend on how the frame is cut into launches.
+  if (const char *mb = std::getenv("PTW_STAGE_BUDGET_MB")) {
+    const long v = std::strtol(mb, nullptr, 10);
+    if (v > 0) ctx->stageBudgetBytes = static_cast<size_t>(v) << 20;
+  }
+  if (const char *kb = std::getenv("PTW_STAGE_BUDGET_KB")) {
+    const long v = std::strtol(kb, nullptr, 10);
+    if (v > 0) ctx->stageBudgetBytes = static_cast<size_t>(v) << 10;
+  }
   ctx->activate();
   *out = ctx.release();
   return PTW_OK;

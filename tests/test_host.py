@@ -1,0 +1,240 @@
+"""CPU: host logic of the hip way - OBJ/MTL loader, scene catalogue, camera, MaterialSpec
+factories, the ArrayOutput file formats.  Loader cases restate test/util/ObjLoaderTests.cpp and
+test/util/ArrayOutputTests.cpp of the reference as data."""
+import hashlib
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+
+def load_text(pkg, text, mtl=None):
+    scene = pkg.Scene()
+    scene.load_obj_text(text, mtl)
+    return scene
+
+
+# ---- ObjLoaderTests.cpp:36-51 "ignores comments and blank lines" ---------------------------
+@pytest.mark.parametrize("text", ["", "\n", "  \n", "  \n  ", "\r", "  \r", "  \r  ", "\r\n",
+                                  "  \r\n", "  \r\n  ", "# comment", "  # comment",
+                                  "  # comment\n#another\n"])
+def test_loader_ignores_comments_and_blank_lines(pkg, text):
+    assert load_text(pkg, text).view().num_triangles == 0
+
+
+# ---- ObjLoaderTests.cpp:52-55 "throws on parse errors" -------------------------------------
+def test_loader_unknown_directive_messages(pkg):
+    with pytest.raises(pkg.PtwError) as e:
+        load_text(pkg, "nope")
+    assert e.value.status == 5 and e.value.message == "Unknown directive 'nope' on line 1"
+    with pytest.raises(pkg.PtwError) as e:
+        load_text(pkg, "\nblargh")
+    assert e.value.message == "Unknown directive 'blargh' on line 2"
+    with pytest.raises(pkg.PtwError) as e:  # vn/vt are not part of the reference's subset
+        load_text(pkg, "v 0 0 0\nvn 0 0 1\n")
+    assert e.value.message == "Unknown directive 'vn' on line 2"
+
+
+# ---- ObjLoaderTests.cpp:57-69 "parses a triangle" ------------------------------------------
+def test_loader_parses_a_triangle_with_negative_indices(pkg):
+    a = load_text(pkg, "\nv 0 0 0\nv 0 0 1\nv 0 1 0\nf -3 -2 -1\n").arrays()
+    assert a["tri_vertices"].tolist() == [[[0, 0, 0], [0, 0, 1], [0, 1, 0]]]
+
+
+def test_loader_fans_faces_and_accepts_slash_indices(pkg):
+    text = "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0.5 2 0 # apex\nf 1/1/1 2/2/2 3/3/3 4/4/4 5//5\n"
+    a = load_text(pkg, text).arrays()
+    assert a["tri_vertices"].shape[0] == 3
+    v = [[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0.5, 2, 0]]
+    assert a["tri_vertices"].tolist() == [[v[0], v[1], v[2]], [v[0], v[2], v[3]], [v[0], v[3], v[4]]]
+    assert load_text(pkg, "g a\no b\ns off\nv 1 2 3 # trailing\n").view().num_triangles == 0
+
+
+def test_loader_error_paths(pkg):
+    for text, status, msg in [
+        ("v 1 2\n", 5, "Wrong number of params for v"),
+        ("usemtl nope\n", 5, "Can't find material nope"),
+        ("mtllib missing.mtl\n", 4, "Unexpected"),
+        ("v 0 0 0\nf 1 2 3\n", 5, None),  # index out of range
+    ]:
+        with pytest.raises(pkg.PtwError) as e:
+            load_text(pkg, text)
+        assert e.value.status == status
+        if msg:
+            assert e.value.message == msg
+    with pytest.raises(pkg.PtwError) as e:
+        pkg.Scene().load_obj("/nonexistent/dir/x.obj")
+    assert e.value.status == 4 and e.value.message.startswith("Unable to open")
+    with pytest.raises(pkg.PtwError) as e:
+        pkg.Scene().build_named("nope", 4, 4)
+    assert e.value.status == 6 and e.value.message == "Unknown scene nope"
+
+
+# ---- ObjLoaderTests.cpp:71-97 "parses materials" -------------------------------------------
+MTL = """
+newmtl leftWall
+  Ns 10.0000
+  Ni 1.5000
+  illum 2
+  Ka 0.63 0.065 0.05 # Red
+  Kd 0.63 0.065 0.05
+  Ks 0 0 0
+  Ke 0 0 0
+
+
+newmtl light
+  Ns 10.0000
+  Ni 1.0000
+  illum 2
+  Ka 0.78 0.78 0.78 # White
+  Kd 0.78 0.78 0.78
+  Ks 0 0 0
+  Ke 17 12 4
+"""
+
+
+def test_loader_parses_materials(pkg):
+    obj = "mtllib x.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl leftWall\nf 1 2 3\nusemtl light\nf 1 2 3\n"
+    a = load_text(pkg, obj, MTL).arrays()
+    left, light = a["materials"][a["tri_material"][0]], a["materials"][a["tri_material"][1]]
+    assert left[3:6].tolist() == [0.63, 0.065, 0.05] and left[0:3].tolist() == [0, 0, 0]
+    assert light[3:6].tolist() == [0.78, 0.78, 0.78] and light[0:3].tolist() == [17, 12, 4]
+    assert left[6] == 1.5 and left[7] == -1 and left[8] == np.pi * 0.9  # Ns 10 -> pi*(1-0.1)
+
+
+def test_loader_illum3_sets_reflectivity_from_ambient(pkg):
+    mtl = "newmtl a\nKa 0.3 0.4 0\nillum 3\nnewmtl b\nKd 1 1 1\n"  # illum/Ka carry into b
+    obj = "mtllib m\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl a\nf 1 2 3\nusemtl b\nf 1 2 3\n"
+    a = load_text(pkg, obj, mtl).arrays()
+    assert a["materials"][a["tri_material"][0]][7] == 0.5
+    assert a["materials"][a["tri_material"][1]][7] == 0.5
+
+
+# ---- scene catalogue vs golden dumps (F3) ---------------------------------------------------
+@pytest.mark.parametrize("name", ["cornell", "suzanne", "ce", "single-sphere", "multi-sphere",
+                                  "example1", "bbc-owl"])
+def test_scene_catalogue_matches_golden(pkg, golden_dir, name):
+    z = np.load(golden_dir / "f3_scenes.npz")
+    scene = pkg.Scene()
+    scene.build_named(name, 64, 48)
+    a = scene.arrays()
+    blob = b"".join(np.ascontiguousarray(a[k]).tobytes() for k in
+                    ("tri_vertices", "tri_material", "sph_centre_radius", "sph_material",
+                     "materials", "environment"))
+    assert [a["tri_vertices"].shape[0], a["sph_centre_radius"].shape[0],
+            a["materials"].shape[0]] == z[f"{name}__counts"].tolist()
+    assert hashlib.sha256(blob).hexdigest() == str(z[f"{name}__sha256"])
+
+
+def test_scene_sizes_recorded_by_the_survey(pkg):
+    """'Scene contains N triangles and M spheres.' as measured with the reference's own
+    StatsSceneBuilder."""
+    for name, want in {"cornell": (38, 1), "suzanne": (970, 2), "ce": (3442, 3)}.items():
+        scene = pkg.Scene()
+        scene.build_named(name, 8, 8)
+        v = scene.view()
+        assert (v.num_triangles, v.num_spheres) == want
+
+
+def test_cornell_arrays_against_golden(pkg, golden_dir):
+    z = np.load(golden_dir / "f3_scenes.npz")
+    scene = pkg.Scene()
+    scene.build_named("cornell", 64, 48)
+    for k, v in scene.arrays().items():
+        assert np.array_equal(v, z[f"cornell__{k}"]), k
+
+
+def test_material_factories(pkg):
+    d = pkg.material("default").as_tuple()
+    assert d == ((0, 0, 0), (0, 0, 0), 1.0, -1.0, 0.0)
+    assert pkg.material("diffuse", (.1, .2, .3)).as_tuple() == ((0, 0, 0), (.1, .2, .3), 1.0, -1.0, 0.0)
+    assert pkg.material("light", (4, 4, 4)).as_tuple() == ((4, 4, 4), (0, 0, 0), 1.0, -1.0, 0.0)
+    assert pkg.material("specular", (.1, .2, .3), 1.3).as_tuple()[2] == 1.3
+    g = pkg.material("glossy", (1, 1, 1), 1.1, 10.0).as_tuple()
+    assert g[2:] == (1.1, -1.0, 10.0 / 360 * 2 * np.pi)
+    r = pkg.material("reflective", (.999, .999, .999), 0.95, 5).as_tuple()
+    assert r[2:] == (1.0, 0.95, 5 / 360 * 2 * np.pi)
+
+
+# ---- camera: the host's ptw_camera drives the oracle to the reference's rays (F8) -----------
+def test_host_camera_reproduces_reference_rays(pkg, ob, golden_dir):
+    z = np.load(golden_dir / "f8_camera.npz")
+    for name, d in ob.SCENE_CAMERAS.items():
+        cam = pkg.Scene().build_named(name, 64, 48)
+        ocam = ob.oracle_camera(d["eye"], d["look_at"], d["up"], 64, 48, d["fov"],
+                                d.get("focus"), d.get("aperture", 0.0))
+        assert np.array_equal(cam.as_array(), ocam.as_array()), name
+        for row in z[name]:
+            got = ob.oracle_camera_ray(cam, int(row[0]), int(row[1]), int(row[2]))
+            assert np.array_equal(got, row[3:]), name
+    cam = pkg.set_focus(pkg.look_at((0, 1, 3), (0, 1, 0), (0, 2, 0), 10, 5, 50.0), (0, 0, 0), 0.01)
+    assert cam.aspect_ratio == 2.0 and cam.reciprocal_width == 0.1 and cam.reciprocal_height == 0.2
+    assert cam.focal_distance == np.sqrt(10.0) and cam.aperture_radius == 0.01
+    assert list(cam.axis_y) == [0, 1, 0]  # `up` is normalised by the call
+
+
+# ---- ArrayOutput surface (F6/F7) -------------------------------------------------------------
+def test_raw_bytes_identical_to_reference(pkg, golden_dir, tmp_path):
+    z = np.load(golden_dir / "f6_raw_png.npz")
+    path = tmp_path / "ours.raw"
+    pkg.raw_save(path, z["rgb_sum"], z["counts"])
+    data = path.read_bytes()
+    assert data == z["raw_bytes"].tobytes()
+    assert len(data) == 16 + 16 * 16 * 28 and struct.unpack("<4I", data[:16]) == (1, 1, 16, 16)
+    rgb, cnt = pkg.raw_load(path)
+    assert np.array_equal(rgb, z["rgb_sum"]) and np.array_equal(cnt, z["counts"])
+    assert pkg.total_samples(cnt) == 16 * 16 * 15
+
+
+def test_rgb8_conversion_identical_to_reference(pkg, ob, golden_dir):
+    z = np.load(golden_dir / "f6_raw_png.npz")
+    assert np.array_equal(pkg.pixels_rgb8(z["rgb_sum"], z["counts"]), z["rgb8"])
+    assert np.array_equal(pkg.pixels_rgb8(z["edge_sum"], z["edge_counts"]), z["edge_rgb8"])
+    for x in (-0.5, 0.0, 0.18, 0.5, 1.0, 7.0):
+        assert ob.component_to_int(x) == pkg.pixels_rgb8(np.full((1, 1, 3), x), np.ones((1, 1), np.uint32))[0, 0, 0]
+
+
+def test_array_output_roundtrip_like_reference_test(pkg, tmp_path):
+    """test/util/ArrayOutputTests.cpp:16-39: 7x5 frame, three pixels set, save, load, compare."""
+    rgb = np.zeros((5, 7, 3))
+    cnt = np.zeros((5, 7), np.uint32)
+    for (x, y, c, n) in [(0, 0, (0.2, 0.3, 0.4), 12), (1, 0, (0.4, 0.6, 0.7), 1), (0, 3, (0.1, 0.2, 0.3), 2)]:
+        rgb[y, x] += c
+        cnt[y, x] += n
+    assert not pkg.pixels_rgb8(np.zeros((20, 10, 3)), np.zeros((20, 10), np.uint32)).any()
+    pkg.raw_save(tmp_path / "a.raw", rgb, cnt)
+    lrgb, lcnt = pkg.raw_load(tmp_path / "a.raw")
+    assert np.array_equal(lrgb, rgb) and np.array_equal(lcnt, cnt)
+    assert np.array_equal(pkg.pixels_rgb8(lrgb, lcnt), pkg.pixels_rgb8(rgb, cnt))
+    # merging two raws = raw_to_png's accumulate (src/main/raw_to_png.cpp:39-58)
+    acc_rgb, acc_cnt = lrgb.copy(), lcnt.copy()
+    rc = pkg.lib.ptw_raw_load_accumulate(str(tmp_path / "a.raw").encode(), 7, 5,
+                                         acc_rgb.ctypes.data, acc_cnt.ctypes.data)
+    assert rc == 0 and np.array_equal(acc_rgb, 2 * rgb) and np.array_equal(acc_cnt, 2 * cnt)
+    rc = pkg.lib.ptw_raw_load_accumulate(str(tmp_path / "a.raw").encode(), 5, 7,
+                                         acc_rgb.ctypes.data, acc_cnt.ctypes.data)
+    assert rc == 7  # PTW_ERR_SIZE_MISMATCH
+    (tmp_path / "bad.raw").write_bytes(struct.pack("<4I", 2, 1, 1, 1))
+    with pytest.raises(pkg.PtwError) as e:
+        pkg.raw_load(tmp_path / "bad.raw")
+    assert "bad signature" in e.value.message
+
+
+def test_png_writer_produces_a_valid_png(pkg, tmp_path):
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    pkg.png_save(tmp_path / "x.png", img)
+    data = (tmp_path / "x.png").read_bytes()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(data):
+        (n,), kind = struct.unpack(">I", data[pos:pos + 4]), data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(kind + body)
+        chunks.append((kind, body))
+        pos += 12 + n
+    assert [k for k, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    assert struct.unpack(">IIBBBBB", chunks[0][1]) == (53, 37, 8, 2, 0, 0, 0)
+    rows = np.frombuffer(zlib.decompress(chunks[1][1]), dtype=np.uint8).reshape(37, 1 + 53 * 3)
+    assert not rows[:, 0].any() and np.array_equal(rows[:, 1:].reshape(37, 53, 3), img)
