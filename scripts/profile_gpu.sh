@@ -1,0 +1,17 @@
+# rocprofv3 evidence for the judged numbers.  Usage (on the GPU box): bash scripts/profile_gpu.sh <tag>
+TAG=${1:-r01}
+cd /tmp && export TMPDIR=/tmp
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+CMD="python $REPO/bench.py --width 256 --height 256 --steps 1 --no-cpu-baseline"
+# 1) kernel trace + stats
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
+# 2) PMC passes (own runs, no tracing)
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAIT_INST_ANY -d $OUT/pmc1 -o pmc1 -- $CMD > $OUT/pmc1.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_IFETCH -d $OUT/pmc2 -o pmc2 -- $CMD > $OUT/pmc2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc3 -o pmc3 -- $CMD > $OUT/pmc3.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc4 -o pmc4 -- $CMD > $OUT/pmc4.log 2>&1
+find $OUT -name "*.csv" | head -30
+for f in $(find $OUT/trace -name "*kernel_stats.csv"); do echo "== $f"; head -12 $f; done
+tail -3 $OUT/*.log
