@@ -36,6 +36,7 @@ import torch.distributed as dist  # noqa: E402
 
 import __graft_entry__ as entry  # noqa: E402
 
+SHARDING = None
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak: 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FLOP_PER_TRI_TEST = 45.0       # Moller-Trumbore incl. 1 division
@@ -74,8 +75,7 @@ def timed_render(ctx, cam, params, rgb, cnt, steps, world, reduce_to_root):
     for _ in range(steps):
         ctx.render(cam, params, rgb.data_ptr(), cnt.data_ptr(), 0, stream)
         if reduce_to_root:
-            dist.reduce(rgb, dst=0, op=dist.ReduceOp.SUM)
-            dist.reduce(cnt, dst=0, op=dist.ReduceOp.SUM)
+            SHARDING.reduce_framebuffer(rgb, cnt, dst=0)  # the one data-path collective (RCCL)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -134,6 +134,9 @@ def main():
     torch.cuda.set_device(local_rank)
 
     pkg = entry.load_package()
+    import importlib
+    global SHARDING
+    SHARDING = importlib.import_module("pt_three_ways_amd.sharding")
     w, h, spp = args.width, args.height, args.spp
     scene = pkg.Scene()
     cam = scene.build_named(args.scene, w, h)
@@ -144,8 +147,9 @@ def main():
 
     policy = pkg.RNG_SEQUENTIAL if args.policy == "sequential" else pkg.RNG_PERPIXEL
     # weak scaling by passes: rank r renders passes [r*spp, (r+1)*spp)
+    first_pass, _ = SHARDING.weak_pass_shard(rank, spp)
     params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=args.seed,
-                                first_pass=rank * spp, rng_policy=policy, device=local_rank)
+                                first_pass=first_pass, rng_policy=policy, device=local_rank)
     rgb = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
     cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
 
