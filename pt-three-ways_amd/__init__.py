@@ -19,7 +19,7 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libptw_hip.so"
+LIB_PATH = Path(os.environ.get("PTW_LIB_PATH", _HERE / "libptw_hip.so"))  # override: A/B builds
 REPO_ROOT = _HERE.parent
 SCENES_DIR = REPO_ROOT / "scenes"
 

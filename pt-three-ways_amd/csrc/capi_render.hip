@@ -66,6 +66,8 @@ struct ptw_context {
   DeviceArray<double> triGeom;
   DeviceArray<TriShade> triShade;
   DeviceArray<SphereRec> spheres;
+  DeviceArray<double> triCompact, matTable;
+  uint32_t nmat = 0;
   DeviceArray<uint32_t> mtState, mtPos;
   DeviceArray<double> stage;
   DeviceArray<unsigned long long> rays; // per-pass intersect() counters, accumulated
@@ -144,6 +146,7 @@ TraceParams makeTraceParams(const ptw_context &ctx, const ptw_camera &cam,
   t.vPow2 = isPowerOfTwo(nV);
   t.ntri = ctx.ntri;
   t.nsph = ctx.nsph;
+  t.nmat = ctx.nmat;
   t.width = p.width;
   t.height = p.height;
   t.maxDepth = p.max_depth;
@@ -208,6 +211,8 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   b.triGeom = ctx.triGeom.ptr;
   b.triShade = ctx.triShade.ptr;
   b.spheres = ctx.spheres.ptr;
+  b.triCompact = ctx.triCompact.ptr;
+  b.matTable = ctx.matTable.ptr;
   b.mtState = ctx.mtState.ptr;
   b.mtPos = ctx.mtPos.ptr;
   b.stage = ctx.stage.ptr;
@@ -293,6 +298,9 @@ int ptw_context_set_scene(ptw_context *ctx, const ptw_scene_view *scene) {
   ctx->triGeom.upload(data.triGeom.data(), data.triGeom.size(), nullptr);
   ctx->triShade.upload(data.triShade.data(), data.triShade.size(), nullptr);
   ctx->spheres.upload(data.spheres.data(), data.spheres.size(), nullptr);
+  ctx->triCompact.upload(data.triCompact.data(), data.triCompact.size(), nullptr);
+  ctx->matTable.upload(data.matTable.data(), data.matTable.size(), nullptr);
+  ctx->nmat = scene->num_materials;
   check(hipStreamSynchronize(nullptr), "scene upload");
   ctx->ntri = scene->num_triangles;
   ctx->nsph = scene->num_spheres;
@@ -371,6 +379,8 @@ int ptw_context_intersect(ptw_context *ctx, const double *rays, uint64_t n, doub
   b.triGeom = ctx->triGeom.ptr;
   b.triShade = ctx->triShade.ptr;
   b.spheres = ctx->spheres.ptr;
+  b.triCompact = ctx->triCompact.ptr;
+  b.matTable = ctx->matTable.ptr;
   check(launchIntersectBatch(t, b, dRays.ptr, n, dHits.ptr, nullptr), "intersect launch");
   check(hipMemcpy(hits_out, dHits.ptr, n * 9 * sizeof(double), hipMemcpyDeviceToHost), "D2H");
   // the kernel reports the combined primitive index; the ABI promises the material index

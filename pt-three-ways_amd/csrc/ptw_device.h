@@ -19,6 +19,54 @@ constexpr double kEpsilon = 0.000000001; // src/math/Epsilon.h:3
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kInf = __builtin_huge_val();
 
+// ---- reciprocal / square roots ------------------------------------------------------------
+// PTW_FAST_MATH (default): v_rcp_f64 / v_rsq_f64 seeds refined by Newton steps in fma form,
+// accurate to about 1 ulp, instead of the ~13 / ~25 instruction IEEE-exact sequences.  They
+// feed only continuous quantities (directions, positions, hit distances); the discrete
+// outcomes of the algorithm (hit/miss, lobe choice) change only if a comparison lands within
+// ~1e-15 relative of its threshold - the same exposure FMA contraction already has - and
+// the radiance VALUE depends only on those discrete outcomes.  Parity tests assert exact RNG
+// word counts, which would expose any systematic effect.  -DPTW_FAST_MATH=0 restores IEEE ops.
+#ifndef PTW_FAST_MATH
+#define PTW_FAST_MATH 1
+#endif
+
+__device__ __forceinline__ double rcp(double x) {
+#if PTW_FAST_MATH
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  return __builtin_fma(y, e, y);
+#else
+  return 1.0 / x;
+#endif
+}
+// 1 / sqrt(x) for x > 0
+__device__ __forceinline__ double rsqrt(double x) {
+#if PTW_FAST_MATH
+  double y = __builtin_amdgcn_rsq(x);
+  double e = __builtin_fma(-(x * y), y, 1.0);
+  y = __builtin_fma(y * 0.5, e, y);
+  e = __builtin_fma(-(x * y), y, 1.0);
+  return __builtin_fma(y * 0.5, e, y);
+#else
+  return 1.0 / __builtin_sqrt(x);
+#endif
+}
+// sqrt(x) for x >= 0
+__device__ __forceinline__ double sqrtPos(double x) {
+#if PTW_FAST_MATH
+  const double y = rsqrt(x);
+  double s = x * y;
+  const double r = __builtin_fma(-s, s, x);
+  s = __builtin_fma(r, 0.5 * y, s);
+  return x == 0.0 ? 0.0 : s;
+#else
+  return __builtin_sqrt(x);
+#endif
+}
+
 struct d3 {
   double x, y, z;
 };
@@ -37,7 +85,7 @@ __device__ __forceinline__ d3 cross(d3 a, d3 b) {
 }
 // Vec3::normalised = *this / length(): multiply by 1.0 / sqrt(dot) (Vec3.h:51-54, impl.h:5-7)
 __device__ __forceinline__ d3 normalised(d3 a) {
-  const double reciprocal = 1.0 / __builtin_sqrt(dot(a, a));
+  const double reciprocal = rsqrt(dot(a, a));
   return mk(a.x * reciprocal, a.y * reciprocal, a.z * reciprocal);
 }
 
@@ -72,30 +120,68 @@ __device__ __forceinline__ double reflectance(d3 n, d3 incoming, double iorFrom,
   const double cosThetaI = -dot(n, incoming);
   const double sinThetaTSquared = iorRatio * iorRatio * (1 - cosThetaI * cosThetaI);
   if (sinThetaTSquared > 1) return 1.0;
-  const double cosThetaT = __builtin_sqrt(1 - sinThetaTSquared);
+  const double cosThetaT = sqrtPos(1 - sinThetaTSquared);
   const double r =
-      (iorFrom * cosThetaI - iorTo * cosThetaT) / (iorFrom * cosThetaI + iorTo * cosThetaT);
+      (iorFrom * cosThetaI - iorTo * cosThetaT) * rcp(iorFrom * cosThetaI + iorTo * cosThetaT);
   return (r * r + r * r) / 2;
+}
+
+// sin and cos of x for the arguments this path produces (theta = 2*pi*u, cone angles: all in
+// [0, 2*pi]).  Cody-Waite reduction by multiples of pi/2 in three exact-product steps, then the
+// classic minimax kernels on [-pi/4, pi/4] (the fdlibm/FreeBSD k_sin / k_cos polynomials,
+// error < 1 ulp).  Arguments outside [0, 6.5] take ocml's sincos (out of line).
+__device__ __noinline__ void sincosGeneral(double x, double *s, double *c) { sincos(x, s, c); }
+
+__device__ __forceinline__ void sinCos(double x, double &sn, double &cs) {
+  if (!(x >= 0.0 && x <= 6.5)) {
+    sincosGeneral(x, &sn, &cs);
+    return;
+  }
+  const double fn = __builtin_rint(x * 6.36619772367581382433e-01); // x * 2/pi -> 0..4
+  // pi/2 = c1 + c2 + c3 (+ ...): c1 has 33 significant bits, so fn * c1 is exact
+  double r = __builtin_fma(-fn, 1.57079632673412561417e+00, x);
+  r = __builtin_fma(-fn, 6.07710050630396597660e-11, r);
+  r = __builtin_fma(-fn, 2.02226624879595063154e-21, r);
+  const double z = r * r;
+  // k_sin
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+               S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+               S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double ps = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, S5), S4), S3), S2);
+  const double ks = __builtin_fma(z * r, __builtin_fma(z, ps, S1), r);
+  // k_cos
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+               C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+               C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double pc = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, C5), C4), C3), C2), C1);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  const double kc = w + (((1.0 - w) - hz) + z * (z * pc));
+  const int q = static_cast<int>(fn) & 3;
+  const double s0 = (q & 1) ? kc : ks;
+  const double c0 = (q & 1) ? ks : kc;
+  sn = (q & 2) ? -s0 : s0;
+  cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
 // hemisphereSample, src/math/Samples.cpp:21-30
 __device__ __forceinline__ d3 hemisphereSample(const Basis &basis, double u, double v) {
   const double theta = (2 * kPi) * u;
-  const double radius = __builtin_sqrt(v);
+  const double radius = sqrtPos(v);
   double s, c;
-  sincos(theta, &s, &c);
-  return normalised(transform(basis, mk(c * radius, s * radius, __builtin_sqrt(1 - v))));
+  sinCos(theta, s, c);
+  return normalised(transform(basis, mk(c * radius, s * radius, sqrtPos(1 - v))));
 }
 
 // coneSample, src/math/Samples.cpp:6-19
-__device__ __forceinline__ d3 coneSample(d3 direction, double coneTheta, double u, double v) {
+__device__ __noinline__ d3 coneSample(d3 direction, double coneTheta, double u, double v) {
   if (coneTheta < kEpsilon) return direction;
   coneTheta = coneTheta * (1.0 - (2.0 * acos(u) / kPi));
   double radius, zScale;
-  sincos(coneTheta, &radius, &zScale);
+  sinCos(coneTheta, radius, zScale);
   const double randomTheta = v * 2 * kPi;
   double s, c;
-  sincos(randomTheta, &s, &c);
+  sinCos(randomTheta, s, c);
   const Basis basis = basisFromZ(direction);
   return normalised(transform(basis, mk(c * radius, s * radius, zScale)));
 }
@@ -140,13 +226,19 @@ __device__ __forceinline__ unsigned dppMoveU(unsigned x) {
 
 // Minimum over the 64 lanes of a wave, returned wave-uniform.  DPP row shifts inside each
 // 16-lane row, then row_bcast15 / row_bcast31 (gfx9-family DPP) into lane 63.
+// v_min_f64 without the v_max(x, x) canonicalisation fmin() adds: inputs are never NaN here.
+__device__ __forceinline__ double vmin64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ double waveMin(double x) {
-  x = fmin(x, dppMove<0x111, 0xf>(x)); // row_shr:1
-  x = fmin(x, dppMove<0x112, 0xf>(x)); // row_shr:2
-  x = fmin(x, dppMove<0x114, 0xf>(x)); // row_shr:4
-  x = fmin(x, dppMove<0x118, 0xf>(x)); // row_shr:8
-  x = fmin(x, dppMove<0x142, 0xa>(x)); // row_bcast:15 -> rows 1,3
-  x = fmin(x, dppMove<0x143, 0xc>(x)); // row_bcast:31 -> rows 2,3
+  x = vmin64(x, dppMove<0x111, 0xf>(x)); // row_shr:1
+  x = vmin64(x, dppMove<0x112, 0xf>(x)); // row_shr:2
+  x = vmin64(x, dppMove<0x114, 0xf>(x)); // row_shr:4
+  x = vmin64(x, dppMove<0x118, 0xf>(x)); // row_shr:8
+  x = vmin64(x, dppMove<0x142, 0xa>(x)); // row_bcast:15 -> rows 1,3
+  x = vmin64(x, dppMove<0x143, 0xc>(x)); // row_bcast:31 -> rows 2,3
   return readLane(x, 63);
 }
 __device__ __forceinline__ unsigned waveMinU(unsigned x) {

@@ -15,7 +15,7 @@ struct TraceParams {
   double env[3];
   double invFirstBounce; // 1.0 / (fbU * fbV)
   double invU, invV;     // 1.0 / fbU, 1.0 / fbV (used when they are powers of two)
-  uint32_t ntri, nsph;
+  uint32_t ntri, nsph, nmat, padA;
   int32_t width, height;
   int32_t maxDepth, fbU, fbV, preview;
   int32_t uPow2, vPow2;
@@ -31,6 +31,8 @@ struct TraceBuffers {
   const double *triGeom;     // [ntri][9]: v0, e1 = v1 - v0, e2 = v2 - v0
   const TriShade *triShade;  // [ntri]
   const SphereRec *spheres;  // [nsph]
+  const double *triCompact;  // [ntri][kTriCompactDoubles]  (copied into LDS by traceSequential)
+  const double *matTable;    // [nmat][kMatDoubles]
   uint32_t *mtState;         // [npass][624] raw mt19937 state (SEQUENTIAL)
   uint32_t *mtPos;           // [npass] next canonical double (0..312; 312 = regenerate)
   double *stage;             // [npass][pixCount][3] this band's per-pass radiance

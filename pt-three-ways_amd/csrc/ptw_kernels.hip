@@ -25,6 +25,10 @@
 #include "ptw_device.h"
 #include "ptw_kernels.h"
 
+#ifndef PTW_SEQ_SINGLE_LOOP
+#define PTW_SEQ_SINGLE_LOOP 0
+#endif
+
 namespace ptw {
 using namespace ptwd;
 
@@ -58,7 +62,7 @@ __device__ __forceinline__ void testTriangle(d3 o, d3 d, d3 v0, d3 e1, d3 e2, ui
   const d3 pVec = cross(d, e2);
   const double det = dot(e1, pVec);
   if (__builtin_fabs(det) < kEpsilon) return;
-  const double invDet = 1.0 / det;
+  const double invDet = rcp(det);
   const d3 tVec = o - v0;
   const double u = dot(tVec, pVec) * invDet;
   const d3 qVec = cross(tVec, e1);
@@ -79,7 +83,7 @@ __device__ __forceinline__ void testSphere(d3 o, d3 d, d3 centre, double radiusS
   const double b = dot(op, d);
   double determinant = b * b - dot(op, op) + radiusSquared;
   if (determinant < 0) return;
-  determinant = __builtin_sqrt(determinant);
+  determinant = sqrtPos(determinant);
   const double minusT = b - determinant;
   const double plusT = b + determinant;
   if (minusT < kEpsilon && plusT < kEpsilon) return;
@@ -154,7 +158,7 @@ __device__ __forceinline__ void cameraRay(const ptw_camera &c, int px, int py, d
   const double angle = r2 * (2 * kPi - 0) + 0;      // uniform_real_distribution(0, 2*pi)
   const double radius = r3 * (c.aperture_radius - 0) + 0;
   double sn, cs;
-  sincos(angle, &sn, &cs);
+  sinCos(angle, sn, cs);
   const d3 origin = (centre + (ax * cs) * radius) + (ay * sn) * radius;
   o = origin;
   d = normalised(focalPoint - origin); // Ray::fromTwoPoints, Ray.h:12-15
@@ -204,11 +208,10 @@ __device__ __forceinline__ d3 radianceChain(CTX &ctx, const TraceParams &p,
       L = ld3(p.env);
       break;
     }
-    const Surface s = makeSurface(p, triShade, spheres, k, o, d);
+    const Surface s = ctx.surfaceAt(k, o, d);
     // numUSamples == numVSamples == 1: (0 + xi) / 1.0 == xi exactly
-    const double u = ctx.draw();
-    const double v = ctx.draw();
-    const double pd = ctx.draw();
+    double u, v, pd;
+    ctx.draw3(u, v, pd);
     d3 nd;
     const bool refl = scatter(ctx, s, d, u, v, pd, nd);
     ctx.push(nlev++, s.emission, s.diffuse, refl);
@@ -230,18 +233,19 @@ __device__ __forceinline__ d3 radiance0(CTX &ctx, const TraceParams &p, const Tr
   if (p.maxDepth <= 0) return mk(0, 0, 0);
   const HitKey k = ctx.intersect(o, d);
   if (ctx.branch(k.idx == kMiss)) return ld3(p.env);
-  const Surface s = makeSurface(p, triShade, spheres, k, o, d);
+  const Surface s = ctx.surfaceAt(k, o, d);
   if (p.preview) return s.diffuse; // Scene.cpp:137-138
   d3 result = mk(0, 0, 0);
   for (int uS = 0; uS < p.fbU; ++uS) {
     for (int vS = 0; vS < p.fbV; ++vS) {
       // (double(uSample) + unit(rng)) / double(numUSamples): a power-of-two divisor is an exact
       // scaling, so multiply by its reciprocal; otherwise divide.
-      const double ur = static_cast<double>(uS) + ctx.draw();
+      double xu, xv, pd;
+      ctx.draw3(xu, xv, pd);
+      const double ur = static_cast<double>(uS) + xu;
       const double u = p.uPow2 ? ur * p.invU : ur / static_cast<double>(p.fbU);
-      const double vr = static_cast<double>(vS) + ctx.draw();
+      const double vr = static_cast<double>(vS) + xv;
       const double v = p.vPow2 ? vr * p.invV : vr / static_cast<double>(p.fbV);
-      const double pd = ctx.draw();
       d3 nd;
       const bool refl = scatter(ctx, s, d, u, v, pd, nd);
       const d3 child = radianceChain(ctx, p, triShade, spheres, s.pos, nd);
@@ -298,7 +302,16 @@ __device__ __noinline__ void mtRegenerateWave(SeqShared *sh, int lane) {
   waveSync();
 }
 
-template <int SLOTS, int WAVES>
+// Shading tables in LDS (filled once per launch): compact triangle records, the material
+// table and the sphere records.  A hit costs one LDS round trip instead of a scalar + vector
+// global fetch on the critical path of every ray.
+struct SeqTables {
+  const double *tri;     // [ntri][kTriCompactDoubles]   (LDS or global)
+  const double *mat;     // [nmat][kMatDoubles]           (LDS or global)
+  const SphereRec *sph;  // [nsph]                        (LDS or global)
+};
+
+template <int SLOTS, int WAVES, bool LDS_TABLES>
 struct SeqCtx {
   static constexpr int kThreads = 64 * WAVES;
 
@@ -312,7 +325,8 @@ struct SeqCtx {
 
   const TraceParams *p;
   const double *triGeom;
-  const SphereRec *spheres;
+  const SphereRec *spheresGlobal;
+  SeqTables tab;
   SeqShared *sh;
   Level *stack;          // this wave's private radiance stack in LDS
   PartialHit *partials;  // [2][WAVES] cross-wave exchange (WAVES > 1)
@@ -321,8 +335,6 @@ struct SeqCtx {
   unsigned words;        // RNG words consumed by the current sample
   unsigned long long rays;
   unsigned parity;
-
-  __device__ __forceinline__ bool branch(bool b) const { return uniformBool(b); }
 
   __device__ __forceinline__ void loadPrimitives() {
     const uint32_t ntri = p->ntri;
@@ -342,7 +354,7 @@ struct SeqCtx {
     }
     hasSphere = static_cast<uint32_t>(tid) < p->nsph;
     if (hasSphere) {
-      const SphereRec &r = spheres[tid];
+      const SphereRec &r = spheresGlobal[tid];
       scx = r.centre[0], scy = r.centre[1], scz = r.centre[2], sr2 = r.radiusSquared;
     } else {
       scx = scy = scz = sr2 = 0;
@@ -371,16 +383,35 @@ struct SeqCtx {
     words += 2;
     return sh->canon[pos++];
   }
-
-  __device__ __forceinline__ void push(int level, d3 e, d3 dif, bool refl) {
-    // every lane stores the same (wave-uniform) value, so each lane reads back its own write
-    Level lv;
-    lv.emission = e;
-    lv.diffuse = dif;
-    lv.reflective = refl;
-    stack[level] = lv;
+  // consecutive draws with one LDS round trip when they do not straddle a regeneration
+  __device__ __forceinline__ void draw3(double &a, double &b, double &c) {
+    if (pos + 3 <= kMtDoubles) {
+      a = sh->canon[pos];
+      b = sh->canon[pos + 1];
+      c = sh->canon[pos + 2];
+      pos += 3;
+      words += 6;
+    } else {
+      a = draw();
+      b = draw();
+      c = draw();
+    }
   }
-  __device__ __forceinline__ Level top(int level) const { return stack[level]; }
+  __device__ __forceinline__ void draw4(double &a, double &b, double &c, double &d) {
+    if (pos + 4 <= kMtDoubles) {
+      a = sh->canon[pos];
+      b = sh->canon[pos + 1];
+      c = sh->canon[pos + 2];
+      d = sh->canon[pos + 3];
+      pos += 4;
+      words += 8;
+    } else {
+      a = draw();
+      b = draw();
+      c = draw();
+      d = draw();
+    }
+  }
 
   // Scene::intersect, Scene.cpp:115-122, cooperatively.
   __device__ __forceinline__ HitKey intersect(d3 o, d3 d) {
@@ -390,20 +421,22 @@ struct SeqCtx {
     const uint32_t nsph = p->nsph;
     // spheres first (lower combined index)
     if (hasSphere) testSphere(o, d, mk(scx, scy, scz), sr2, static_cast<uint32_t>(tid), bestT, bestIdx);
-    for (uint32_t i = tid + kThreads; i < nsph; i += kThreads) { // rare: > 64*WAVES spheres
-      const SphereRec &r = spheres[i];
-      testSphere(o, d, ld3(r.centre), r.radiusSquared, i, bestT, bestIdx);
-    }
+    if (nsph > static_cast<uint32_t>(kThreads)) // rare: more spheres than lanes
+      for (uint32_t i = tid + kThreads; i < nsph; i += kThreads) {
+        const SphereRec &r = spheresGlobal[i];
+        testSphere(o, d, ld3(r.centre), r.radiusSquared, i, bestT, bestIdx);
+      }
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s)
       testTriangle(o, d, mk(v0x[s], v0y[s], v0z[s]), mk(e1x[s], e1y[s], e1z[s]),
                    mk(e2x[s], e2y[s], e2z[s]), nsph + static_cast<uint32_t>(tid) * SLOTS + s,
                    bestT, bestIdx, bestDet);
     // rare: more triangles than resident slots -> stream the remainder from memory
-    for (uint32_t k = static_cast<uint32_t>(kThreads) * SLOTS + tid; k < p->ntri; k += kThreads) {
-      const double *g = triGeom + 9 * static_cast<size_t>(k);
-      testTriangle(o, d, ld3(g), ld3(g + 3), ld3(g + 6), nsph + k, bestT, bestIdx, bestDet);
-    }
+    if (p->ntri > static_cast<uint32_t>(kThreads) * SLOTS)
+      for (uint32_t k = static_cast<uint32_t>(kThreads) * SLOTS + tid; k < p->ntri; k += kThreads) {
+        const double *g = triGeom + 9 * static_cast<size_t>(k);
+        testTriangle(o, d, ld3(g), ld3(g + 3), ld3(g + 6), nsph + k, bestT, bestIdx, bestDet);
+      }
 
     // wave reduction: lexicographic min of (t, idx)
     const double tmin = waveMin(bestT);
@@ -411,13 +444,18 @@ struct SeqCtx {
     if (tmin == kInf) {
       key.t = kInf, key.idx = kMiss, key.det = 0;
     } else {
-      const uint32_t cand = bestT == tmin ? bestIdx : kMiss;
-      const uint32_t imin = waveMinU(cand);
-      const unsigned long long owner = __builtin_amdgcn_ballot_w64(bestIdx == imin);
-      const int lane = __builtin_ctzll(owner);
+      unsigned long long owner = __builtin_amdgcn_ballot_w64(bestT == tmin);
+      uint32_t imin;
+      if (__builtin_popcountll(owner) == 1) { // the usual case: a unique nearest lane
+        imin = static_cast<uint32_t>(
+            __builtin_amdgcn_readlane(static_cast<int>(bestIdx), __builtin_ctzll(owner)));
+      } else { // exact tie between lanes: lowest combined index wins
+        imin = waveMinU(bestT == tmin ? bestIdx : kMiss);
+        owner = __builtin_amdgcn_ballot_w64(bestIdx == imin);
+      }
       key.t = tmin;
       key.idx = imin;
-      key.det = readLane(bestDet, lane);
+      key.det = readLane(bestDet, __builtin_ctzll(owner));
     }
     if (WAVES > 1) {
       PartialHit *slot = partials + (parity & 1u) * WAVES;
@@ -443,30 +481,204 @@ struct SeqCtx {
     }
     return key;
   }
+
+  __device__ __forceinline__ bool branch(bool b) const { return uniformBool(b); }
+  __device__ __forceinline__ void push(int level, d3 e, d3 dif, bool refl) {
+    Level lv;
+    lv.emission = e;
+    lv.diffuse = dif;
+    lv.reflective = refl;
+    stack[level] = lv; // every lane stores the same wave-uniform value
+  }
+  __device__ __forceinline__ Level top(int level) const { return stack[level]; }
+
+  // Surface at a hit from the shading tables (same values as makeSurface()).
+  __device__ __forceinline__ Surface surfaceAt(const HitKey &k, d3 o, d3 d) const {
+    Surface s;
+    s.pos = o + d * k.t;
+    double ior, invIor, reflectivity;
+    bool inside;
+    if (k.idx >= p->nsph) {
+      const double *r = tab.tri + static_cast<size_t>(k.idx - p->nsph) * kTriCompactDoubles;
+      const bool backfacing = k.det < kEpsilon;
+      const d3 n = ld3(r), bx = ld3(r + 3);
+      s.normal = backfacing ? -n : n;
+      s.basis.x = backfacing ? -bx : bx;
+      s.basis.y = ld3(r + 6);
+      s.basis.z = s.normal;
+      const double *m = tab.mat + static_cast<size_t>(static_cast<uint32_t>(r[9])) * kMatDoubles;
+      s.emission = ld3(m);
+      s.diffuse = ld3(m + 3);
+      ior = m[6], invIor = m[7], reflectivity = m[8];
+      s.coneAngle = m[9];
+      inside = backfacing;
+    } else {
+      const SphereRec &r = tab.sph[k.idx];
+      d3 n = normalised(s.pos - ld3(r.centre));
+      inside = dot(n, d) > 0;
+      if (inside) n = -n;
+      s.normal = n;
+      s.basis = basisFromZ(n);
+      s.emission = ld3(r.emission);
+      s.diffuse = ld3(r.diffuse);
+      s.coneAngle = r.coneAngle;
+      ior = r.ior, invIor = r.invIor, reflectivity = r.reflectivity;
+    }
+    const double iorFrom = inside ? ior : 1.0;
+    const double iorTo = inside ? 1.0 : ior;
+    const double iorRatio = inside ? ior : invIor;
+    s.reflectivity =
+        reflectivity < 0 ? reflectance(s.normal, d, iorFrom, iorTo, iorRatio) : reflectivity;
+    return s;
+  }
+
+  // One camera path (Scene.cpp:124-179 for depth 0 and its fan-out) as ONE loop with a single
+  // intersect / surface / scatter site.  k = depth of the surface we are about to scatter from
+  // (-1: no surface yet, the ray is the camera ray).
+  __device__ __forceinline__ d3 samplePath(d3 o, d3 d) {
+    const TraceParams &P = *p;
+    Surface cur{}, first{};
+    d3 dirIn = d, dirFirst = d;
+    d3 result = mk(0, 0, 0);
+    bool reflFirst = false;
+    int k = -1, nlev = 0, sub = 0;
+    const int nSub = P.fbU * P.fbV;
+    for (;;) {
+      if (k >= 0) {
+        double xu, xv, pd;
+        draw3(xu, xv, pd);
+        double u = xu, v = xv;
+        if (k == 0) { // (double(uSample) + xi) / double(numUSamples), Scene.cpp:157-160
+          const int uS = sub / P.fbV, vS = sub - uS * P.fbV;
+          const double ur = static_cast<double>(uS) + xu, vr = static_cast<double>(vS) + xv;
+          u = P.uPow2 ? ur * P.invU : ur / static_cast<double>(P.fbU);
+          v = P.vPow2 ? vr * P.invV : vr / static_cast<double>(P.fbV);
+        }
+        d3 nd;
+        bool refl;
+        if (uniformBool(pd < cur.reflectivity)) { // Scene.cpp:163-168
+          nd = coneSample(reflect(cur.normal, dirIn), cur.coneAngle, u, v);
+          refl = true;
+        } else {
+          nd = hemisphereSample(cur.basis, u, v);
+          refl = false;
+        }
+        if (k == 0) {
+          reflFirst = refl;
+        } else {
+          Level lv;
+          lv.emission = cur.emission;
+          lv.diffuse = cur.diffuse;
+          lv.reflective = refl;
+          stack[nlev++] = lv; // every lane stores the same wave-uniform value
+        }
+        o = cur.pos;
+        d = nd;
+      }
+      const int depth = k + 1;
+      d3 term;
+      bool terminated;
+      if (depth >= P.maxDepth) { // Scene.cpp:128
+        term = mk(0, 0, 0);
+        terminated = true;
+      } else {
+        const HitKey key = intersect(o, d);
+        if (uniformBool(key.idx == kMiss)) { // Scene.cpp:131-133
+          term = ld3(P.env);
+          terminated = true;
+        } else {
+          cur = surfaceAt(key, o, d);
+          dirIn = d;
+          terminated = P.preview != 0; // Scene.cpp:137-138 (only reachable at depth 0)
+          term = cur.diffuse;
+        }
+      }
+      if (!terminated) {
+        if (depth == 0) {
+          first = cur;
+          dirFirst = d;
+        }
+        k = depth;
+        continue;
+      }
+      if (depth == 0) return term;
+      // fold the chain innermost-first: L_d = E_d + T_d * L_{d+1}
+      d3 L = term;
+      for (int i = nlev - 1; i >= 0; --i) {
+        const Level lv = stack[i];
+        L = uniformBool(lv.reflective) ? lv.emission + L : lv.emission + lv.diffuse * L;
+      }
+      result = result + (reflFirst ? first.emission + L : first.emission + first.diffuse * L);
+      if (++sub == nSub) return result * P.invFirstBounce;
+      cur = first;
+      dirIn = dirFirst;
+      k = 0;
+      nlev = 0;
+    }
+  }
 };
 
-template <int SLOTS, int WAVES>
+// Bytes of dynamic LDS traceSequential needs (also computed on the host for the launch).
+__host__ __device__ inline size_t seqLdsBytes(int waves, int maxDepth, bool ldsTables, uint32_t ntri,
+                                              uint32_t nmat, uint32_t nsph) {
+  size_t n = sizeof(SeqShared);
+  n += static_cast<size_t>(waves) * (maxDepth > 0 ? maxDepth : 1) * sizeof(Level);
+  n += 2 * static_cast<size_t>(waves) * sizeof(PartialHit);
+  n = (n + 63) & ~static_cast<size_t>(63);
+  if (ldsTables) {
+    n += static_cast<size_t>(nsph) * sizeof(SphereRec);
+    n += static_cast<size_t>(ntri) * kTriCompactDoubles * sizeof(double);
+    n += static_cast<size_t>(nmat) * kMatDoubles * sizeof(double);
+  }
+  return n;
+}
+
+template <int SLOTS, int WAVES, bool LDS_TABLES>
 __global__ __launch_bounds__(64 * WAVES) void traceSequential(
     const TraceParams p, const double *__restrict__ triGeom,
     const TriShade *__restrict__ triShade, const SphereRec *__restrict__ spheres,
+    const double *__restrict__ triCompact, const double *__restrict__ matTable,
     uint32_t *__restrict__ mtState, uint32_t *__restrict__ mtPos, double *__restrict__ stage,
     uint32_t *__restrict__ words, unsigned long long *__restrict__ rayCounters) {
-  __shared__ SeqShared sh;
-  __shared__ Level stacks[WAVES][kMaxDepth];
-  __shared__ PartialHit partials[2 * WAVES];
+  extern __shared__ __attribute__((aligned(64))) unsigned char ldsRaw[];
+  (void)triShade;
+  const int depthSlots = p.maxDepth > 0 ? p.maxDepth : 1;
+  SeqShared &sh = *reinterpret_cast<SeqShared *>(ldsRaw);
+  Level *stacks = reinterpret_cast<Level *>(ldsRaw + sizeof(SeqShared));
+  PartialHit *partials = reinterpret_cast<PartialHit *>(stacks + WAVES * depthSlots);
+  size_t off = sizeof(SeqShared) + static_cast<size_t>(WAVES) * depthSlots * sizeof(Level) +
+               2 * static_cast<size_t>(WAVES) * sizeof(PartialHit);
+  off = (off + 63) & ~static_cast<size_t>(63);
 
   const int pass = blockIdx.x;
-  SeqCtx<SLOTS, WAVES> ctx;
+  SeqCtx<SLOTS, WAVES, LDS_TABLES> ctx;
   ctx.p = &p;
   ctx.triGeom = triGeom;
-  ctx.spheres = spheres;
+  ctx.spheresGlobal = spheres;
   ctx.sh = &sh;
   ctx.tid = threadIdx.x;
-  ctx.stack = stacks[threadIdx.x >> 6];
+  ctx.stack = stacks + (threadIdx.x >> 6) * depthSlots;
   ctx.partials = partials;
   ctx.words = 0;
   ctx.rays = 0;
   ctx.parity = 0;
+  if (LDS_TABLES) {
+    SphereRec *ls = reinterpret_cast<SphereRec *>(ldsRaw + off);
+    double *lt = reinterpret_cast<double *>(ls + p.nsph);
+    double *lm = lt + static_cast<size_t>(p.ntri) * kTriCompactDoubles;
+    const double *gs = reinterpret_cast<const double *>(spheres);
+    double *lsd = reinterpret_cast<double *>(ls);
+    for (uint32_t i = threadIdx.x; i < p.nsph * (sizeof(SphereRec) / 8); i += 64 * WAVES) lsd[i] = gs[i];
+    for (uint32_t i = threadIdx.x; i < p.ntri * kTriCompactDoubles; i += 64 * WAVES) lt[i] = triCompact[i];
+    for (uint32_t i = threadIdx.x; i < p.nmat * kMatDoubles; i += 64 * WAVES) lm[i] = matTable[i];
+    ctx.tab.sph = ls;
+    ctx.tab.tri = lt;
+    ctx.tab.mat = lm;
+  } else {
+    ctx.tab.sph = spheres;
+    ctx.tab.tri = triCompact;
+    ctx.tab.mat = matTable;
+  }
   ctx.loadPrimitives();
 
   // resume this pass's generator
@@ -484,16 +696,20 @@ __global__ __launch_bounds__(64 * WAVES) void traceSequential(
     const int px = static_cast<int>(pix % static_cast<uint32_t>(w));
     const int py = static_cast<int>(pix / static_cast<uint32_t>(w));
     ctx.words = 0;
-    const double r0 = ctx.draw();
-    const double r1 = ctx.draw();
-    double r2 = 0, r3 = 0;
+    double r0, r1, r2 = 0, r3 = 0;
     if (lens) {
-      r2 = ctx.draw();
-      r3 = ctx.draw();
+      ctx.draw4(r0, r1, r2, r3);
+    } else {
+      r0 = ctx.draw();
+      r1 = ctx.draw();
     }
     d3 o, d;
     cameraRay(p.cam, px, py, r0, r1, r2, r3, o, d);
+#if PTW_SEQ_SINGLE_LOOP
+    const d3 L = ctx.samplePath(o, d);
+#else
     const d3 L = radiance0(ctx, p, triShade, spheres, o, d);
+#endif
     if (threadIdx.x == 0) {
       myStage[i * 3 + 0] = L.x;
       myStage[i * 3 + 1] = L.y;
@@ -518,7 +734,11 @@ __global__ __launch_bounds__(64 * WAVES) void traceSequential(
 struct PixCtx {
   const TraceParams *p;
   const double *triGeom;
+  const TriShade *triShade;
   const SphereRec *spheres;
+  __device__ __forceinline__ Surface surfaceAt(const HitKey &k, d3 o, d3 d) const {
+    return makeSurface(*p, triShade, spheres, k, o, d);
+  }
   Sfc32 rng;
   unsigned words;
   unsigned long long rays;
@@ -530,6 +750,11 @@ struct PixCtx {
     const uint32_t w1 = rng.next();
     words += 2;
     return canonicalFromWords(w0, w1);
+  }
+  __device__ __forceinline__ void draw3(double &a, double &b, double &c) {
+    a = draw();
+    b = draw();
+    c = draw();
   }
   __device__ __forceinline__ void push(int level, d3 e, d3 dif, bool refl) {
     Level lv;
@@ -576,6 +801,7 @@ __global__ __launch_bounds__(kPixBlock) void tracePerPixel(
   PixCtx ctx;
   ctx.p = &p;
   ctx.triGeom = triGeom;
+  ctx.triShade = triShade;
   ctx.spheres = spheres;
   ctx.words = 0;
   ctx.rays = 0;
@@ -629,6 +855,7 @@ __global__ __launch_bounds__(256) void intersectBatchKernel(
   PixCtx ctx;
   ctx.p = &p;
   ctx.triGeom = triGeom;
+  ctx.triShade = triShade;
   ctx.spheres = spheres;
   ctx.rays = 0;
   const d3 o = ld3(rays + gid * 6), d = ld3(rays + gid * 6 + 3);
@@ -686,12 +913,31 @@ __global__ __launch_bounds__(64) void rngKatKernel(int rngPolicy,
   }
 }
 
-template <int SLOTS, int WAVES>
+constexpr size_t kLdsTableBudget = 96 * 1024; // bytes of LDS we are willing to spend on tables
+
+template <int SLOTS, int WAVES, bool LDS_TABLES>
 hipError_t launchSeq(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
-  hipLaunchKernelGGL((traceSequential<SLOTS, WAVES>), dim3(p.npass), dim3(64 * WAVES), 0, stream,
-                     p, b.triGeom, b.triShade, b.spheres, b.mtState, b.mtPos, b.stage, b.words,
+  auto kernel = traceSequential<SLOTS, WAVES, LDS_TABLES>;
+  const size_t lds = seqLdsBytes(WAVES, p.maxDepth, LDS_TABLES, p.ntri, p.nmat, p.nsph);
+  static size_t configured = 0; // per instantiation
+  if (lds > 48 * 1024 && lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    configured = lds;
+  }
+  hipLaunchKernelGGL(kernel, dim3(p.npass), dim3(64 * WAVES), lds, stream, p, b.triGeom, b.triShade,
+                     b.spheres, b.triCompact, b.matTable, b.mtState, b.mtPos, b.stage, b.words,
                      b.rays);
   return hipGetLastError();
+}
+
+template <int SLOTS, int WAVES>
+hipError_t launchSeqAuto(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
+  const size_t tables = seqLdsBytes(WAVES, p.maxDepth, true, p.ntri, p.nmat, p.nsph);
+  if (tables <= kLdsTableBudget) return launchSeq<SLOTS, WAVES, true>(p, b, stream);
+  return launchSeq<SLOTS, WAVES, false>(p, b, stream);
 }
 
 } // namespace
@@ -700,13 +946,13 @@ hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hi
   const uint32_t n = p.ntri;
   // Smallest resident configuration that holds every triangle in VGPRs; 1 wave up to 128
   // triangles, otherwise 4 waves (one per SIMD of a CU) with up to 16 slots per lane.
-  if (n <= 64) return launchSeq<1, 1>(p, b, stream);
-  if (n <= 128) return launchSeq<2, 1>(p, b, stream);
-  if (n <= 256) return launchSeq<1, 4>(p, b, stream);
-  if (n <= 512) return launchSeq<2, 4>(p, b, stream);
-  if (n <= 1024) return launchSeq<4, 4>(p, b, stream);
-  if (n <= 2048) return launchSeq<8, 4>(p, b, stream);
-  return launchSeq<16, 4>(p, b, stream); // beyond 4096 the tail is streamed from memory
+  if (n <= 64) return launchSeqAuto<1, 1>(p, b, stream);
+  if (n <= 128) return launchSeqAuto<2, 1>(p, b, stream);
+  if (n <= 256) return launchSeqAuto<1, 4>(p, b, stream);
+  if (n <= 512) return launchSeqAuto<2, 4>(p, b, stream);
+  if (n <= 1024) return launchSeqAuto<4, 4>(p, b, stream);
+  if (n <= 2048) return launchSeqAuto<8, 4>(p, b, stream);
+  return launchSeqAuto<16, 4>(p, b, stream); // beyond 4096 the tail is streamed from memory
 }
 
 hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {

@@ -38,6 +38,13 @@ struct alignas(64) SphereRec {
   double pad[2];
 }; // 16 doubles = 128 B
 
+// Compact per-triangle record for the LDS-resident shading table of the SEQUENTIAL kernel:
+// normal, basisX, basisY (as in TriShade) + the material index as a double.  Materials sit in
+// their own table of kMatDoubles doubles each: emission, diffuse, ior, 1/ior, reflectivity,
+// cone angle.
+constexpr int kTriCompactDoubles = 10;
+constexpr int kMatDoubles = 10;
+
 constexpr int kMtWords = 624;
 constexpr int kMtDoubles = 312; // canonical doubles per regeneration (2 words each)
 constexpr int kMaxDepth = 64;   // radiance stack capacity (levels kept in LDS)

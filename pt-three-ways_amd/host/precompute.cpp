@@ -28,6 +28,13 @@ DeviceSceneData precomputeScene(const ptw_scene_view &scene) {
   out.triMaterial.assign(scene.tri_material, scene.tri_material + scene.num_triangles);
   out.sphMaterial.assign(scene.sph_material, scene.sph_material + scene.num_spheres);
 
+  out.triCompact.resize(static_cast<size_t>(scene.num_triangles) * kTriCompactDoubles);
+  out.matTable.resize(static_cast<size_t>(scene.num_materials) * kMatDoubles);
+  for (uint32_t m = 0; m < scene.num_materials; ++m) {
+    double *t = &out.matTable[static_cast<size_t>(m) * kMatDoubles];
+    copyMaterial(scene.materials[m], t, t + 3, t[6], t[7], t[8], t[9]);
+  }
+
   for (uint32_t i = 0; i < scene.num_triangles; ++i) {
     const double *tv = scene.tri_vertices + 9 * static_cast<size_t>(i);
     const Vec3d v0(tv), v1(tv + 3), v2(tv + 6);
@@ -59,6 +66,9 @@ DeviceSceneData precomputeScene(const ptw_scene_view &scene) {
       throw std::runtime_error("triangle material index out of range");
     copyMaterial(scene.materials[scene.tri_material[i]], r.emission, r.diffuse, r.ior, r.invIor,
                  r.reflectivity, r.coneAngle);
+    double *c = &out.triCompact[static_cast<size_t>(i) * kTriCompactDoubles];
+    normal.store(c), bx.store(c + 3), by.store(c + 6);
+    c[9] = static_cast<double>(scene.tri_material[i]);
   }
 
   for (uint32_t i = 0; i < scene.num_spheres; ++i) {

@@ -19,6 +19,8 @@ struct DeviceSceneData {
   std::vector<double> triGeom;      // [ntri][9]: v0, e1, e2
   std::vector<TriShade> triShade;   // [ntri]
   std::vector<SphereRec> spheres;   // [nsph]
+  std::vector<double> triCompact;   // [ntri][kTriCompactDoubles]
+  std::vector<double> matTable;     // [nmat][kMatDoubles]
   std::vector<uint32_t> triMaterial; // [ntri]  (for the intersect KAT entry point)
   std::vector<uint32_t> sphMaterial; // [nsph]
   double environment[3];

@@ -1,5 +1,7 @@
 import sys, time
-sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
 import numpy as np, torch
 import __graft_entry__ as e
 pkg = e.load_package()
