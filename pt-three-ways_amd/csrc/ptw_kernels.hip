@@ -25,6 +25,22 @@
 #include "ptw_device.h"
 #include "ptw_kernels.h"
 
+#include <cstdlib>
+#include <string>
+
+// -DPTW_PROFILE_PHASES=1: debug build that times the phases of the sequential kernel with
+// s_memtime and printf()s the per-ray averages of pass 0 (never enabled in the shipped library).
+#ifndef PTW_PROFILE_PHASES
+#define PTW_PROFILE_PHASES 0
+#endif
+#if PTW_PROFILE_PHASES
+#define PTW_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define PTW_ACC(slot, a, b) prof[slot] += (b) - (a)
+#else
+#define PTW_T(var)
+#define PTW_ACC(slot, a, b)
+#endif
+
 #ifndef PTW_SEQ_SINGLE_LOOP
 #define PTW_SEQ_SINGLE_LOOP 0
 #endif
@@ -203,6 +219,7 @@ __device__ __forceinline__ d3 radianceChain(CTX &ctx, const TraceParams &p,
       L = mk(0, 0, 0);
       break;
     }
+    ctx.prefetch3(); // the three draws the next scatter needs, issued ahead of the search
     const HitKey k = ctx.intersect(o, d);
     if (ctx.branch(k.idx == kMiss)) { // Scene.cpp:131-133
       L = ld3(p.env);
@@ -210,14 +227,17 @@ __device__ __forceinline__ d3 radianceChain(CTX &ctx, const TraceParams &p,
     }
     const Surface s = ctx.surfaceAt(k, o, d);
     // numUSamples == numVSamples == 1: (0 + xi) / 1.0 == xi exactly
+    const unsigned long long tS0 = ctx.now();
     double u, v, pd;
     ctx.draw3(u, v, pd);
     d3 nd;
     const bool refl = scatter(ctx, s, d, u, v, pd, nd);
+    ctx.addScatter(tS0, nd.x);
     ctx.push(nlev++, s.emission, s.diffuse, refl);
     o = s.pos;
     d = nd;
   }
+  ctx.prefetch3(); // for the next first-bounce sample, overlapped with the fold
   // fold: result = 0 + (E + T * child); result / 1 (both exact no-ops on the value)
   for (int i = nlev - 1; i >= 0; --i) {
     const Level lv = ctx.top(i);
@@ -231,6 +251,7 @@ template <typename CTX>
 __device__ __forceinline__ d3 radiance0(CTX &ctx, const TraceParams &p, const TriShade *triShade,
                                         const SphereRec *spheres, d3 o, d3 d) {
   if (p.maxDepth <= 0) return mk(0, 0, 0);
+  ctx.prefetch3();
   const HitKey k = ctx.intersect(o, d);
   if (ctx.branch(k.idx == kMiss)) return ld3(p.env);
   const Surface s = ctx.surfaceAt(k, o, d);
@@ -335,6 +356,22 @@ struct SeqCtx {
   unsigned words;        // RNG words consumed by the current sample
   unsigned long long rays;
   unsigned parity;
+  double pf0, pf1, pf2;  // prefetched canon[pos .. pos+2]
+  bool pfValid;
+#if PTW_PROFILE_PHASES
+  unsigned long long prof[8];
+#endif
+
+  // Issue the LDS reads of the next three draws early (their latency then hides behind the
+  // nearest-hit search); draw3() consumes them.  Reading ahead does not advance the stream.
+  __device__ __forceinline__ void prefetch3() {
+    pfValid = pos + 3 <= kMtDoubles;
+    if (pfValid) {
+      pf0 = sh->canon[pos];
+      pf1 = sh->canon[pos + 1];
+      pf2 = sh->canon[pos + 2];
+    }
+  }
 
   __device__ __forceinline__ void loadPrimitives() {
     const uint32_t ntri = p->ntri;
@@ -376,6 +413,7 @@ struct SeqCtx {
   }
 
   __device__ __forceinline__ double draw() {
+    pfValid = false;
     if (pos == kMtDoubles) {
       regenerate();
       pos = 0;
@@ -385,7 +423,12 @@ struct SeqCtx {
   }
   // consecutive draws with one LDS round trip when they do not straddle a regeneration
   __device__ __forceinline__ void draw3(double &a, double &b, double &c) {
-    if (pos + 3 <= kMtDoubles) {
+    if (pfValid) {
+      a = pf0, b = pf1, c = pf2;
+      pos += 3;
+      words += 6;
+      pfValid = false;
+    } else if (pos + 3 <= kMtDoubles) {
       a = sh->canon[pos];
       b = sh->canon[pos + 1];
       c = sh->canon[pos + 2];
@@ -398,6 +441,7 @@ struct SeqCtx {
     }
   }
   __device__ __forceinline__ void draw4(double &a, double &b, double &c, double &d) {
+    pfValid = false;
     if (pos + 4 <= kMtDoubles) {
       a = sh->canon[pos];
       b = sh->canon[pos + 1];
@@ -416,6 +460,7 @@ struct SeqCtx {
   // Scene::intersect, Scene.cpp:115-122, cooperatively.
   __device__ __forceinline__ HitKey intersect(d3 o, d3 d) {
     rays++;
+    PTW_T(tA);
     double bestT = kInf, bestDet = 0;
     uint32_t bestIdx = kMiss;
     const uint32_t nsph = p->nsph;
@@ -439,6 +484,11 @@ struct SeqCtx {
       }
 
     // wave reduction: lexicographic min of (t, idx)
+#if PTW_PROFILE_PHASES
+    asm volatile("" : "+v"(bestT));
+#endif
+    PTW_T(tB);
+    PTW_ACC(0, tA, tB);
     const double tmin = waveMin(bestT);
     HitKey key;
     if (tmin == kInf) {
@@ -479,10 +529,25 @@ struct SeqCtx {
       key.det = readFirstLane(best.det);
       key.idx = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(best.idx)));
     }
+#if PTW_PROFILE_PHASES
+    asm volatile("" : "+v"(key.t));
+#endif
+    PTW_T(tC);
+    PTW_ACC(1, tB, tC);
     return key;
   }
 
   __device__ __forceinline__ bool branch(bool b) const { return uniformBool(b); }
+#if PTW_PROFILE_PHASES
+  __device__ __forceinline__ unsigned long long now() const { return __builtin_amdgcn_s_memtime(); }
+  __device__ __forceinline__ void addScatter(unsigned long long t0, double &keep) {
+    asm volatile("" : "+v"(keep));
+    prof[3] += __builtin_amdgcn_s_memtime() - t0;
+  }
+#else
+  __device__ __forceinline__ unsigned long long now() const { return 0; }
+  __device__ __forceinline__ void addScatter(unsigned long long, double &) {}
+#endif
   __device__ __forceinline__ void push(int level, d3 e, d3 dif, bool refl) {
     Level lv;
     lv.emission = e;
@@ -493,7 +558,8 @@ struct SeqCtx {
   __device__ __forceinline__ Level top(int level) const { return stack[level]; }
 
   // Surface at a hit from the shading tables (same values as makeSurface()).
-  __device__ __forceinline__ Surface surfaceAt(const HitKey &k, d3 o, d3 d) const {
+  __device__ __forceinline__ Surface surfaceAt(const HitKey &k, d3 o, d3 d) {
+    PTW_T(tA);
     Surface s;
     s.pos = o + d * k.t;
     double ior, invIor, reflectivity;
@@ -529,6 +595,11 @@ struct SeqCtx {
     const double iorRatio = inside ? ior : invIor;
     s.reflectivity =
         reflectivity < 0 ? reflectance(s.normal, d, iorFrom, iorTo, iorRatio) : reflectivity;
+#if PTW_PROFILE_PHASES
+    asm volatile("" : "+v"(s.reflectivity), "+v"(s.pos.x), "+v"(s.basis.y.z), "+v"(s.diffuse.x));
+#endif
+    PTW_T(tB);
+    PTW_ACC(2, tA, tB);
     return s;
   }
 
@@ -662,6 +733,8 @@ __global__ __launch_bounds__(64 * WAVES) void traceSequential(
   ctx.words = 0;
   ctx.rays = 0;
   ctx.parity = 0;
+  ctx.pfValid = false;
+  ctx.pf0 = ctx.pf1 = ctx.pf2 = 0;
   if (LDS_TABLES) {
     SphereRec *ls = reinterpret_cast<SphereRec *>(ldsRaw + off);
     double *lt = reinterpret_cast<double *>(ls + p.nsph);
@@ -691,6 +764,10 @@ __global__ __launch_bounds__(64 * WAVES) void traceSequential(
   const int w = p.width;
   const bool lens = p.cam.aperture_radius != 0;
   double *myStage = stage + static_cast<size_t>(pass) * p.pixCount * 3;
+#if PTW_PROFILE_PHASES
+  for (int i = 0; i < 8; ++i) ctx.prof[i] = 0;
+  const unsigned long long tStart = __builtin_amdgcn_s_memtime();
+#endif
   for (uint32_t i = 0; i < p.pixCount; ++i) {
     const uint32_t pix = p.pixBegin + i;
     const int px = static_cast<int>(pix % static_cast<uint32_t>(w));
@@ -718,6 +795,16 @@ __global__ __launch_bounds__(64 * WAVES) void traceSequential(
     }
   }
 
+#if PTW_PROFILE_PHASES
+  if (pass == 0 && threadIdx.x == 0) {
+    const unsigned long long tEnd = __builtin_amdgcn_s_memtime();
+    const double r = static_cast<double>(ctx.rays);
+    printf("PHASES rays=%llu total/ray=%.0f tests=%.0f reduce=%.0f surface=%.0f scatter=%.0f other=%.0f\n",
+           ctx.rays, (tEnd - tStart) / r, ctx.prof[0] / r, ctx.prof[1] / r, ctx.prof[2] / r,
+           ctx.prof[3] / r,
+           ((tEnd - tStart) - ctx.prof[0] - ctx.prof[1] - ctx.prof[2] - ctx.prof[3]) / r);
+  }
+#endif
   // park the generator for the next band
   __syncthreads();
   for (int i = threadIdx.x; i < kMtWords; i += 64 * WAVES) myState[i] = sh.mt[i];
@@ -731,6 +818,17 @@ __global__ __launch_bounds__(64 * WAVES) void traceSequential(
 // PERPIXEL policy: one lane per (pass, pixel) sample; primitives streamed from memory with
 // wave-uniform addresses (every lane of a wave tests the same triangle).
 // -----------------------------------------------------------------------------------------
+struct TriRegs {
+  double v[9]; // v0, e1, e2
+};
+__device__ __forceinline__ TriRegs loadTriUniform(const double *__restrict__ triGeom, uint32_t k) {
+  TriRegs t;
+  const double *g = triGeom + 9 * static_cast<size_t>(k);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) t.v[i] = g[i];
+  return t;
+}
+
 struct PixCtx {
   const TraceParams *p;
   const double *triGeom;
@@ -751,6 +849,9 @@ struct PixCtx {
     words += 2;
     return canonicalFromWords(w0, w1);
   }
+  __device__ __forceinline__ void prefetch3() {}
+  __device__ __forceinline__ unsigned long long now() const { return 0; }
+  __device__ __forceinline__ void addScatter(unsigned long long, double &) {}
   __device__ __forceinline__ void draw3(double &a, double &b, double &c) {
     a = draw();
     b = draw();
@@ -774,9 +875,40 @@ struct PixCtx {
       const SphereRec &r = spheres[i];
       testSphere(o, d, ld3(r.centre), r.radiusSquared, i, key.t, key.idx);
     }
-    for (uint32_t k = 0; k < ntri; ++k) {
-      const double *g = triGeom + 9 * static_cast<size_t>(k);
-      testTriangle(o, d, ld3(g), ld3(g + 3), ld3(g + 6), nsph + k, key.t, key.idx, key.det);
+    if (ntri < 128) { // short lists: the plain loop (compiler-scheduled) is fastest
+      for (uint32_t k = 0; k < ntri; ++k) {
+        const double *g = triGeom + 9 * static_cast<size_t>(k);
+        testTriangle(o, d, ld3(g), ld3(g + 3), ld3(g + 6), nsph + k, key.t, key.idx, key.det);
+      }
+    } else {
+      // wave-uniform scalar loads, one triangle ahead (see tracePerPixelPersistent)
+      TriRegs cur = loadTriUniform(triGeom, 0);
+      for (uint32_t k = 0; k < ntri; ++k) {
+        const d3 e1 = mk(cur.v[3], cur.v[4], cur.v[5]), e2 = mk(cur.v[6], cur.v[7], cur.v[8]);
+        const d3 v0 = mk(cur.v[0], cur.v[1], cur.v[2]);
+        const d3 pVec = cross(d, e2);
+        const double det = dot(e1, pVec);
+        __builtin_amdgcn_sched_barrier(0);
+        const TriRegs nxt = loadTriUniform(triGeom, k + 1 < ntri ? k + 1 : k);
+        __builtin_amdgcn_sched_barrier(0);
+        // per-lane early-outs: coherent rays reject whole triangles at wave level
+        if (!(__builtin_fabs(det) < kEpsilon)) {
+          const double invDet = rcp(det);
+          const d3 tVec = o - v0;
+          const double u = dot(tVec, pVec) * invDet;
+          const d3 qVec = cross(tVec, e1);
+          const double v = dot(d, qVec) * invDet;
+          if (!((u < 0.0) | (u > 1.0) | (v < 0.0) | (u + v > 1))) {
+            const double t = dot(e2, qVec) * invDet;
+            if (t > kEpsilon && t < key.t) {
+              key.t = t;
+              key.idx = nsph + k;
+              key.det = det;
+            }
+          }
+        }
+        cur = nxt;
+      }
     }
     return key;
   }
@@ -824,6 +956,287 @@ __global__ __launch_bounds__(kPixBlock) void tracePerPixel(
   out[0] = L.x, out[1] = L.y, out[2] = L.z;
   if (words) words[static_cast<size_t>(pass) * p.npix + pix] = ctx.words;
   if (rayCounters) atomicAdd(&rayCounters[pass], ctx.rays);
+}
+
+// -----------------------------------------------------------------------------------------
+// PERPIXEL policy, persistent form: every lane owns a queue of (pass, pixel) samples and runs
+// the path state machine; each trip of the outer loop traces ONE ray per lane against all
+// primitives, then every lane advances its own path (shade, scatter, fold, start the next
+// sample) until it again holds a ray to trace.  Lanes whose paths end early immediately pick
+// up the next sample instead of idling until the slowest lane of the wave is done.
+// Triangles are streamed with wave-uniform scalar loads, double-buffered one triangle ahead
+// so the SMEM latency hides behind the ~45 VALU instructions of a Moller-Trumbore test.
+// -----------------------------------------------------------------------------------------
+constexpr int kPix2Block = 256;
+
+__global__ __launch_bounds__(kPix2Block) void tracePerPixelPersistent(
+    const TraceParams p, const double *__restrict__ triGeom,
+    const SphereRec *__restrict__ spheres, const double *__restrict__ triCompact,
+    const double *__restrict__ matTable, double *__restrict__ stage, uint32_t *__restrict__ words,
+    unsigned long long *__restrict__ rayCounters) {
+  extern __shared__ uint32_t pixLevels[]; // [maxDepth][blockDim.x]: (material << 1) | reflective
+  const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
+  const uint64_t lanes = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  uint64_t sample = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  uint32_t *myLevels = pixLevels + threadIdx.x;
+  const uint32_t nsph = p.nsph, ntri = p.ntri;
+  const int nSub = p.fbU * p.fbV;
+
+  // ---- per-lane path state ----
+  Sfc32 rng;
+  unsigned nwords = 0;
+  unsigned long long nrays = 0;
+  d3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+  int depth = 0;      // depth of the ray currently held
+  int sub = 0, nlev = 0;
+  bool reflFirst = false;
+  Surface first{};
+  uint32_t firstMat = 0; // unused placeholder to keep Surface self-contained
+  d3 dirFirst = d;
+  d3 result = mk(0, 0, 0);
+  uint32_t pass = 0, pixIdx = 0;
+  bool active = sample < total;
+  (void)firstMat;
+
+  // Starts sample `sample`: seeds the stream, draws the camera ray.  Returns false when a
+  // sample needs no tracing at all (maxDepth <= 0) - handled by the caller's loop.
+  auto beginSample = [&]() {
+    pass = static_cast<uint32_t>(sample / p.pixCount);
+    pixIdx = static_cast<uint32_t>(sample % p.pixCount);
+    const uint32_t pix = p.pixBegin + pixIdx;
+    rng.seed(p.passSeedBase + pass, pix);
+    nwords = 0;
+    auto draw = [&]() {
+      const uint32_t w0 = rng.next();
+      const uint32_t w1 = rng.next();
+      nwords += 2;
+      return canonicalFromWords(w0, w1);
+    };
+    const int px = static_cast<int>(pix % static_cast<uint32_t>(p.width));
+    const int py = static_cast<int>(pix / static_cast<uint32_t>(p.width));
+    const double r0 = draw();
+    const double r1 = draw();
+    double r2 = 0, r3 = 0;
+    if (p.cam.aperture_radius != 0) {
+      r2 = draw();
+      r3 = draw();
+    }
+    cameraRay(p.cam, px, py, r0, r1, r2, r3, o, d);
+    depth = 0;
+  };
+  auto finishSample = [&](d3 L) {
+    double *out = stage + (static_cast<size_t>(pass) * p.pixCount + pixIdx) * 3;
+    out[0] = L.x, out[1] = L.y, out[2] = L.z;
+    if (words) words[static_cast<size_t>(pass) * p.npix + p.pixBegin + pixIdx] = nwords;
+    sample += lanes;
+    active = sample < total;
+  };
+
+  if (active) {
+    beginSample();
+    while (active && p.maxDepth <= 0) { // degenerate: radiance() returns 0 without tracing
+      finishSample(mk(0, 0, 0));
+      if (active) beginSample();
+    }
+  }
+
+  while (__builtin_amdgcn_ballot_w64(active) != 0) {
+    // ------------------------------------------------------------------ trace one ray / lane
+    HitKey key;
+    key.t = kInf, key.idx = kMiss, key.det = 0;
+    if (active) {
+      nrays++;
+      for (uint32_t i = 0; i < nsph; ++i) {
+        const SphereRec &r = spheres[i];
+        testSphere(o, d, ld3(r.centre), r.radiusSquared, i, key.t, key.idx);
+      }
+      if (ntri) {
+        TriRegs cur = loadTriUniform(triGeom, 0);
+        for (uint32_t k = 0; k < ntri; ++k) {
+          // first part of the test uses e1/e2 of `cur`; then the next triangle's loads are put
+          // in flight; the rest of the test runs while they land.
+          const d3 e1 = mk(cur.v[3], cur.v[4], cur.v[5]), e2 = mk(cur.v[6], cur.v[7], cur.v[8]);
+          const d3 v0 = mk(cur.v[0], cur.v[1], cur.v[2]);
+          const d3 pVec = cross(d, e2);
+          const double det = dot(e1, pVec);
+          __builtin_amdgcn_sched_barrier(0);
+          const TriRegs nxt = loadTriUniform(triGeom, k + 1 < ntri ? k + 1 : k);
+          __builtin_amdgcn_sched_barrier(0);
+          if (!(__builtin_fabs(det) < kEpsilon)) {
+            const double invDet = rcp(det);
+            const d3 tVec = o - v0;
+            const double u = dot(tVec, pVec) * invDet;
+            const d3 qVec = cross(tVec, e1);
+            const double v = dot(d, qVec) * invDet;
+            if (!((u < 0.0) | (u > 1.0) | (v < 0.0) | (u + v > 1))) {
+              const double t = dot(e2, qVec) * invDet;
+              if (t > kEpsilon && t < key.t) {
+                key.t = t;
+                key.idx = nsph + k;
+                key.det = det;
+              }
+            }
+          }
+          cur = nxt;
+        }
+      }
+    }
+
+    // ------------------------------------------------- advance this lane's path to its next ray
+    if (active) {
+      bool haveHitResult = true;
+      for (;;) {
+        d3 term = mk(0, 0, 0);
+        bool terminated = false;
+        if (haveHitResult) {
+          haveHitResult = false;
+          if (key.idx == kMiss) {
+            term = ld3(p.env);
+            terminated = true;
+          } else {
+            // surface at the hit (per-lane gather of the compact record + material)
+            Surface s;
+            s.pos = o + d * key.t;
+            double ior, invIor, reflectivity;
+            bool inside;
+            if (key.idx >= nsph) {
+              const double *r = triCompact + static_cast<size_t>(key.idx - nsph) * kTriCompactDoubles;
+              const bool backfacing = key.det < kEpsilon;
+              const d3 n = ld3(r), bx = ld3(r + 3);
+              s.normal = backfacing ? -n : n;
+              s.basis.x = backfacing ? -bx : bx;
+              s.basis.y = ld3(r + 6);
+              s.basis.z = s.normal;
+              const double *m = matTable + static_cast<size_t>(static_cast<uint32_t>(r[9])) * kMatDoubles;
+              s.emission = ld3(m);
+              s.diffuse = ld3(m + 3);
+              ior = m[6], invIor = m[7], reflectivity = m[8];
+              s.coneAngle = m[9];
+              inside = backfacing;
+            } else {
+              const SphereRec &r = spheres[key.idx];
+              d3 n = normalised(s.pos - ld3(r.centre));
+              inside = dot(n, d) > 0;
+              if (inside) n = -n;
+              s.normal = n;
+              s.basis = basisFromZ(n);
+              s.emission = ld3(r.emission);
+              s.diffuse = ld3(r.diffuse);
+              s.coneAngle = r.coneAngle;
+              ior = r.ior, invIor = r.invIor, reflectivity = r.reflectivity;
+            }
+            const double iorFrom = inside ? ior : 1.0;
+            const double iorTo = inside ? 1.0 : ior;
+            const double iorRatio = inside ? ior : invIor;
+            s.reflectivity = reflectivity < 0
+                                 ? reflectance(s.normal, d, iorFrom, iorTo, iorRatio)
+                                 : reflectivity;
+            if (p.preview) {
+              term = s.diffuse;
+              terminated = true;
+            } else if (depth == 0) {
+              first = s;
+              dirFirst = d;
+              sub = 0;
+              result = mk(0, 0, 0);
+              // falls through to "scatter from first" below
+            } else {
+              // scatter from s (single-sample level): u = xi, v = xi
+              const uint32_t w0 = rng.next(), w1 = rng.next(), w2 = rng.next(), w3 = rng.next(),
+                             w4 = rng.next(), w5 = rng.next();
+              nwords += 6;
+              const double u = canonicalFromWords(w0, w1), v = canonicalFromWords(w2, w3),
+                           pd = canonicalFromWords(w4, w5);
+              d3 nd;
+              bool refl;
+              if (pd < s.reflectivity) {
+                nd = coneSample(reflect(s.normal, d), s.coneAngle, u, v);
+                refl = true;
+              } else {
+                nd = hemisphereSample(s.basis, u, v);
+                refl = false;
+              }
+              // push (emission, diffuse) by value: two 3-vectors per level in LDS
+              double *lv = reinterpret_cast<double *>(pixLevels) +
+                           (static_cast<size_t>(nlev) * blockDim.x + threadIdx.x) * 7;
+              lv[0] = s.emission.x, lv[1] = s.emission.y, lv[2] = s.emission.z;
+              lv[3] = s.diffuse.x, lv[4] = s.diffuse.y, lv[5] = s.diffuse.z;
+              lv[6] = refl ? 1.0 : 0.0;
+              nlev++;
+              o = s.pos;
+              d = nd;
+              depth++;
+              if (depth < p.maxDepth) break; // have a ray to trace
+              terminated = true;             // depth cap: radiance() returns 0 (Scene.cpp:128)
+              term = mk(0, 0, 0);
+            }
+          }
+        }
+        if (terminated) {
+          if (depth == 0) { // primary ray missed / preview
+            finishSample(term);
+            if (!active) break;
+            beginSample();
+            break;
+          }
+          // fold innermost-first
+          d3 L = term;
+          for (int i = nlev - 1; i >= 0; --i) {
+            const double *lv = reinterpret_cast<const double *>(pixLevels) +
+                               (static_cast<size_t>(i) * blockDim.x + threadIdx.x) * 7;
+            const d3 e = mk(lv[0], lv[1], lv[2]), df = mk(lv[3], lv[4], lv[5]);
+            L = lv[6] != 0.0 ? e + L : e + df * L;
+          }
+          result = result + (reflFirst ? first.emission + L : first.emission + first.diffuse * L);
+          if (++sub == nSub) {
+            finishSample(result * p.invFirstBounce);
+            if (!active) break;
+            beginSample();
+            break;
+          }
+        }
+        // scatter from the first-bounce surface: sub-sample `sub`
+        {
+          const uint32_t w0 = rng.next(), w1 = rng.next(), w2 = rng.next(), w3 = rng.next(),
+                         w4 = rng.next(), w5 = rng.next();
+          nwords += 6;
+          const double xu = canonicalFromWords(w0, w1), xv = canonicalFromWords(w2, w3),
+                       pd = canonicalFromWords(w4, w5);
+          const int uS = sub / p.fbV, vS = sub - uS * p.fbV;
+          const double ur = static_cast<double>(uS) + xu, vr = static_cast<double>(vS) + xv;
+          const double u = p.uPow2 ? ur * p.invU : ur / static_cast<double>(p.fbU);
+          const double v = p.vPow2 ? vr * p.invV : vr / static_cast<double>(p.fbV);
+          d3 nd;
+          if (pd < first.reflectivity) {
+            nd = coneSample(reflect(first.normal, dirFirst), first.coneAngle, u, v);
+            reflFirst = true;
+          } else {
+            nd = hemisphereSample(first.basis, u, v);
+            reflFirst = false;
+          }
+          o = first.pos;
+          d = nd;
+          depth = 1;
+          nlev = 0;
+          if (depth < p.maxDepth) break; // trace it
+          // maxDepth == 1: the child is radiance(depth 1) = 0; loop to terminate this sub-sample
+          // with term = 0 (zero-initialised at the top of the loop)
+          // (terminated path handled at the top of the next trip)
+          haveHitResult = false;
+          // emulate: terminated with term = 0
+          d3 L0 = mk(0, 0, 0);
+          result = result + (reflFirst ? first.emission + L0 : first.emission + first.diffuse * L0);
+          if (++sub == nSub) {
+            finishSample(result * p.invFirstBounce);
+            if (!active) break;
+            beginSample();
+            break;
+          }
+        }
+      }
+    }
+  }
+  if (rayCounters && nrays) atomicAdd(&rayCounters[0], nrays);
 }
 
 // -----------------------------------------------------------------------------------------
@@ -956,6 +1369,27 @@ hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hi
 }
 
 hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
+  // Small scenes are shading-bound: the lock-step kernel wins.  Larger scenes are bound by the
+  // nearest-hit search, where the persistent kernel's lane re-use pays.  PTW_PIX_KERNEL
+  // (legacy|persistent) overrides for A/B runs.
+  static const char *forced = std::getenv("PTW_PIX_KERNEL");
+  const bool persistent = forced ? std::string(forced) == "persistent" : p.ntri >= 128;
+  if (persistent) {
+    const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    // persistent grid: 4 blocks of 256 lanes per CU (4 waves per SIMD), fewer for tiny jobs
+    uint64_t blocks = static_cast<uint64_t>(cus) * 4;
+    const uint64_t needed = (total + kPix2Block - 1) / kPix2Block;
+    if (blocks > needed) blocks = needed;
+    const int levels = p.maxDepth > 1 ? p.maxDepth - 1 : 1;
+    const size_t lds = static_cast<size_t>(levels) * kPix2Block * 7 * sizeof(double);
+    hipLaunchKernelGGL(tracePerPixelPersistent, dim3(static_cast<uint32_t>(blocks)),
+                       dim3(kPix2Block), lds, stream, p, b.triGeom, b.spheres, b.triCompact,
+                       b.matTable, b.stage, b.words, b.rays);
+    return hipGetLastError();
+  }
   const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
   const uint32_t blocks = static_cast<uint32_t>((total + kPixBlock - 1) / kPixBlock);
   const int levels = p.maxDepth > 1 ? p.maxDepth - 1 : 1;
