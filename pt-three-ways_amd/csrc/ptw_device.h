@@ -117,6 +117,9 @@ __device__ __forceinline__ d3 reflect(d3 n, d3 incoming) {
 // passed in (the host precomputes 1/ior with the same correctly rounded division).
 __device__ __forceinline__ double reflectance(d3 n, d3 incoming, double iorFrom, double iorTo,
                                               double iorRatio) {
+#if PTW_ABLATE == 2
+  return 0.0 * iorFrom * iorTo * iorRatio * dot(n, incoming);
+#endif
   const double cosThetaI = -dot(n, incoming);
   const double sinThetaTSquared = iorRatio * iorRatio * (1 - cosThetaI * cosThetaI);
   if (sinThetaTSquared > 1) return 1.0;
@@ -164,13 +167,37 @@ __device__ __forceinline__ void sinCos(double x, double &sn, double &cs) {
   cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
+// normalised() for a vector whose length is 1 up to rounding (|len^2 - 1| << 1e-7):
+// 1/sqrt(1 + e) = 1 - e/2 + O(e^2), and the O(e^2) term is below half an ulp.
+__device__ __forceinline__ d3 normalisedNearUnit(d3 a) {
+#if PTW_FAST_MATH
+  const double reciprocal = __builtin_fma(-0.5, dot(a, a) - 1.0, 1.0);
+  return mk(a.x * reciprocal, a.y * reciprocal, a.z * reciprocal);
+#else
+  return normalised(a);
+#endif
+}
+
 // hemisphereSample, src/math/Samples.cpp:21-30
+#ifndef PTW_ABLATE
+#define PTW_ABLATE 0 // timing experiments only: 1 = no sincos, 2 = no reflectance, 3 = no sqrt in sampling
+#endif
 __device__ __forceinline__ d3 hemisphereSample(const Basis &basis, double u, double v) {
   const double theta = (2 * kPi) * u;
+#if PTW_ABLATE == 3
+  const double radius = v;
+#else
   const double radius = sqrtPos(v);
+#endif
   double s, c;
+#if PTW_ABLATE == 1
+  s = theta * 0.1; c = 1.0 - s;
+#else
   sinCos(theta, s, c);
-  return normalised(transform(basis, mk(c * radius, s * radius, sqrtPos(1 - v))));
+#endif
+  // (c r, s r, sqrt(1 - v)) has squared length v + (1 - v) and the basis is orthonormal, so the
+  // transformed vector is unit length up to a few ulp
+  return normalisedNearUnit(transform(basis, mk(c * radius, s * radius, sqrtPos(1 - v))));
 }
 
 // coneSample, src/math/Samples.cpp:6-19
@@ -241,6 +268,32 @@ __device__ __forceinline__ double waveMin(double x) {
   x = vmin64(x, dppMove<0x143, 0xc>(x)); // row_bcast:31 -> rows 2,3
   return readLane(x, 63);
 }
+// Wave-wide unsigned minimum with the DPP operand fused into v_min_u32 (one VALU op per step;
+// lanes whose DPP source is outside the row / masked rows are not written and keep their own
+// value).  `s_nop 1` covers the VALU-write -> DPP-read hazard inside the asm block.
+__device__ __forceinline__ unsigned waveMinUFused(unsigned x) {
+  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+               "s_nop 1"
+               : "+v"(x));
+  return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(x), 63));
+}
+// Minimum of non-negative doubles (or +inf) over the wave: their IEEE bit patterns order like
+// unsigned 64-bit integers, so reduce the high words, then the low words of the lanes that hold
+// the minimal high word.
+__device__ __forceinline__ double waveMinPositive(double x, unsigned &hiOut, unsigned &loOut) {
+  const unsigned hi = static_cast<unsigned>(hi32(x)), lo = static_cast<unsigned>(lo32(x));
+  const unsigned mhi = waveMinUFused(hi);
+  const unsigned mlo = waveMinUFused(hi == mhi ? lo : 0xffffffffu);
+  hiOut = mhi;
+  loOut = mlo;
+  return mk64(static_cast<int>(mlo), static_cast<int>(mhi));
+}
+
 __device__ __forceinline__ unsigned waveMinU(unsigned x) {
   x = min(x, dppMoveU<0x111, 0xf>(x));
   x = min(x, dppMoveU<0x112, 0xf>(x));

@@ -489,18 +489,20 @@ struct SeqCtx {
 #endif
     PTW_T(tB);
     PTW_ACC(0, tA, tB);
-    const double tmin = waveMin(bestT);
+    unsigned tHi, tLo;
+    const double tmin = waveMinPositive(bestT, tHi, tLo);
     HitKey key;
-    if (tmin == kInf) {
+    if (tHi == 0x7ff00000u) { // +inf: no lane has a hit
       key.t = kInf, key.idx = kMiss, key.det = 0;
     } else {
-      unsigned long long owner = __builtin_amdgcn_ballot_w64(bestT == tmin);
+      unsigned long long owner = __builtin_amdgcn_ballot_w64(
+          static_cast<unsigned>(hi32(bestT)) == tHi && static_cast<unsigned>(lo32(bestT)) == tLo);
       uint32_t imin;
       if (__builtin_popcountll(owner) == 1) { // the usual case: a unique nearest lane
         imin = static_cast<uint32_t>(
             __builtin_amdgcn_readlane(static_cast<int>(bestIdx), __builtin_ctzll(owner)));
       } else { // exact tie between lanes: lowest combined index wins
-        imin = waveMinU(bestT == tmin ? bestIdx : kMiss);
+        imin = waveMinUFused(bestT == tmin ? bestIdx : kMiss);
         owner = __builtin_amdgcn_ballot_w64(bestIdx == imin);
       }
       key.t = tmin;
