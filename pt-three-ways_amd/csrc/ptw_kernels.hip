@@ -41,9 +41,6 @@
 #define PTW_ACC(slot, a, b)
 #endif
 
-#ifndef PTW_SEQ_SINGLE_LOOP
-#define PTW_SEQ_SINGLE_LOOP 0
-#endif
 
 namespace ptw {
 using namespace ptwd;
@@ -219,7 +216,6 @@ __device__ __forceinline__ d3 radianceChain(CTX &ctx, const TraceParams &p,
       L = mk(0, 0, 0);
       break;
     }
-    ctx.prefetch3(); // the three draws the next scatter needs, issued ahead of the search
     const HitKey k = ctx.intersect(o, d);
     if (ctx.branch(k.idx == kMiss)) { // Scene.cpp:131-133
       L = ld3(p.env);
@@ -228,16 +224,13 @@ __device__ __forceinline__ d3 radianceChain(CTX &ctx, const TraceParams &p,
     const Surface s = ctx.surfaceAt(k, o, d);
     // numUSamples == numVSamples == 1: (0 + xi) / 1.0 == xi exactly
     const unsigned long long tS0 = ctx.now();
-    double u, v, pd;
-    ctx.draw3(u, v, pd);
     d3 nd;
-    const bool refl = scatter(ctx, s, d, u, v, pd, nd);
+    const bool refl = ctx.scatterChain(s, d, nd);
     ctx.addScatter(tS0, nd.x);
     ctx.push(nlev++, s.emission, s.diffuse, refl);
     o = s.pos;
     d = nd;
   }
-  ctx.prefetch3(); // for the next first-bounce sample, overlapped with the fold
   // fold: result = 0 + (E + T * child); result / 1 (both exact no-ops on the value)
   for (int i = nlev - 1; i >= 0; --i) {
     const Level lv = ctx.top(i);
@@ -251,7 +244,6 @@ template <typename CTX>
 __device__ __forceinline__ d3 radiance0(CTX &ctx, const TraceParams &p, const TriShade *triShade,
                                         const SphereRec *spheres, d3 o, d3 d) {
   if (p.maxDepth <= 0) return mk(0, 0, 0);
-  ctx.prefetch3();
   const HitKey k = ctx.intersect(o, d);
   if (ctx.branch(k.idx == kMiss)) return ld3(p.env);
   const Surface s = ctx.surfaceAt(k, o, d);
@@ -282,6 +274,12 @@ __device__ __forceinline__ d3 radiance0(CTX &ctx, const TraceParams &p, const Tr
 struct SeqShared {
   uint32_t mt[kMtWords];
   double canon[kMtDoubles];
+  // For every position q of the block: the local cosine-hemisphere direction that
+  // hemisphereSample() builds from (u, v) = (canon[q], canon[q + 1]) before the basis transform:
+  // (cos(2 pi u) sqrt(v), sin(2 pi u) sqrt(v), sqrt(1 - v)).  It depends only on the draws, so all
+  // positions are evaluated 64 lanes at a time when the block is generated, instead of one
+  // sincos + two square roots on the serial path of every bounce.
+  double hemi[kMtDoubles][3];
 };
 
 struct PartialHit {
@@ -297,6 +295,19 @@ struct PartialHit {
 // fences keep the compiler from reordering one lane's loads across another lane's stores.
 // Kept out of line: it runs once per 312 draws and would otherwise be cloned into every
 // draw() site.
+__device__ __forceinline__ void fillHemiTable(SeqShared *sh, int lane) {
+  for (int q = lane; q + 1 < kMtDoubles; q += 64) {
+    const double u = sh->canon[q], v = sh->canon[q + 1];
+    const double theta = (2 * kPi) * u;
+    const double radius = sqrtPos(v);
+    double sn, cs;
+    sinCos(theta, sn, cs);
+    sh->hemi[q][0] = cs * radius;
+    sh->hemi[q][1] = sn * radius;
+    sh->hemi[q][2] = sqrtPos(1 - v);
+  }
+}
+
 __device__ __noinline__ void mtRegenerateWave(SeqShared *sh, int lane) {
   uint32_t *x = sh->mt;
   waveSync();
@@ -320,6 +331,8 @@ __device__ __noinline__ void mtRegenerateWave(SeqShared *sh, int lane) {
   waveSync();
   for (int i = lane; i < kMtDoubles; i += 64)
     sh->canon[i] = canonicalFromWords(mtTemper(x[2 * i]), mtTemper(x[2 * i + 1]));
+  waveSync();
+  fillHemiTable(sh, lane);
   waveSync();
 }
 
@@ -356,22 +369,9 @@ struct SeqCtx {
   unsigned words;        // RNG words consumed by the current sample
   unsigned long long rays;
   unsigned parity;
-  double pf0, pf1, pf2;  // prefetched canon[pos .. pos+2]
-  bool pfValid;
 #if PTW_PROFILE_PHASES
   unsigned long long prof[8];
 #endif
-
-  // Issue the LDS reads of the next three draws early (their latency then hides behind the
-  // nearest-hit search); draw3() consumes them.  Reading ahead does not advance the stream.
-  __device__ __forceinline__ void prefetch3() {
-    pfValid = pos + 3 <= kMtDoubles;
-    if (pfValid) {
-      pf0 = sh->canon[pos];
-      pf1 = sh->canon[pos + 1];
-      pf2 = sh->canon[pos + 2];
-    }
-  }
 
   __device__ __forceinline__ void loadPrimitives() {
     const uint32_t ntri = p->ntri;
@@ -406,14 +406,16 @@ struct SeqCtx {
 
   // Rebuild canon[] from the current raw state without twisting (state resumed mid-block).
   __device__ __forceinline__ void rebuildCanon() {
-    if (tid < 64)
+    if (tid < 64) {
       for (int i = tid; i < kMtDoubles; i += 64)
         sh->canon[i] = canonicalFromWords(mtTemper(sh->mt[2 * i]), mtTemper(sh->mt[2 * i + 1]));
+      waveSync();
+      fillHemiTable(sh, tid);
+    }
     __syncthreads();
   }
 
   __device__ __forceinline__ double draw() {
-    pfValid = false;
     if (pos == kMtDoubles) {
       regenerate();
       pos = 0;
@@ -423,12 +425,7 @@ struct SeqCtx {
   }
   // consecutive draws with one LDS round trip when they do not straddle a regeneration
   __device__ __forceinline__ void draw3(double &a, double &b, double &c) {
-    if (pfValid) {
-      a = pf0, b = pf1, c = pf2;
-      pos += 3;
-      words += 6;
-      pfValid = false;
-    } else if (pos + 3 <= kMtDoubles) {
+    if (pos + 3 <= kMtDoubles) {
       a = sh->canon[pos];
       b = sh->canon[pos + 1];
       c = sh->canon[pos + 2];
@@ -441,7 +438,6 @@ struct SeqCtx {
     }
   }
   __device__ __forceinline__ void draw4(double &a, double &b, double &c, double &d) {
-    pfValid = false;
     if (pos + 4 <= kMtDoubles) {
       a = sh->canon[pos];
       b = sh->canon[pos + 1];
@@ -540,6 +536,28 @@ struct SeqCtx {
   }
 
   __device__ __forceinline__ bool branch(bool b) const { return uniformBool(b); }
+
+  // The scatter of a single-sample level (depth >= 1): u = xi1, v = xi2, p = xi3 drawn in that
+  // order (Scene.cpp:157-161).  When the three draws sit inside the current block, the diffuse
+  // lobe takes its local direction from the precomputed table.
+  __device__ __forceinline__ bool scatterChain(const Surface &s, d3 dirIn, d3 &dirOut) {
+    if (pos + 3 <= kMtDoubles) {
+      const int q = pos;
+      const double pd = sh->canon[q + 2];
+      const d3 local = mk(sh->hemi[q][0], sh->hemi[q][1], sh->hemi[q][2]);
+      pos += 3;
+      words += 6;
+      if (uniformBool(pd < s.reflectivity)) { // Scene.cpp:163-168
+        dirOut = coneSample(reflect(s.normal, dirIn), s.coneAngle, sh->canon[q], sh->canon[q + 1]);
+        return true;
+      }
+      dirOut = normalisedNearUnit(transform(s.basis, local)); // Scene.cpp:169-175
+      return false;
+    }
+    double u, v, pd;
+    draw3(u, v, pd); // straddles a regeneration
+    return scatter(*this, s, dirIn, u, v, pd, dirOut);
+  }
 #if PTW_PROFILE_PHASES
   __device__ __forceinline__ unsigned long long now() const { return __builtin_amdgcn_s_memtime(); }
   __device__ __forceinline__ void addScatter(unsigned long long t0, double &keep) {
@@ -604,91 +622,6 @@ struct SeqCtx {
     PTW_ACC(2, tA, tB);
     return s;
   }
-
-  // One camera path (Scene.cpp:124-179 for depth 0 and its fan-out) as ONE loop with a single
-  // intersect / surface / scatter site.  k = depth of the surface we are about to scatter from
-  // (-1: no surface yet, the ray is the camera ray).
-  __device__ __forceinline__ d3 samplePath(d3 o, d3 d) {
-    const TraceParams &P = *p;
-    Surface cur{}, first{};
-    d3 dirIn = d, dirFirst = d;
-    d3 result = mk(0, 0, 0);
-    bool reflFirst = false;
-    int k = -1, nlev = 0, sub = 0;
-    const int nSub = P.fbU * P.fbV;
-    for (;;) {
-      if (k >= 0) {
-        double xu, xv, pd;
-        draw3(xu, xv, pd);
-        double u = xu, v = xv;
-        if (k == 0) { // (double(uSample) + xi) / double(numUSamples), Scene.cpp:157-160
-          const int uS = sub / P.fbV, vS = sub - uS * P.fbV;
-          const double ur = static_cast<double>(uS) + xu, vr = static_cast<double>(vS) + xv;
-          u = P.uPow2 ? ur * P.invU : ur / static_cast<double>(P.fbU);
-          v = P.vPow2 ? vr * P.invV : vr / static_cast<double>(P.fbV);
-        }
-        d3 nd;
-        bool refl;
-        if (uniformBool(pd < cur.reflectivity)) { // Scene.cpp:163-168
-          nd = coneSample(reflect(cur.normal, dirIn), cur.coneAngle, u, v);
-          refl = true;
-        } else {
-          nd = hemisphereSample(cur.basis, u, v);
-          refl = false;
-        }
-        if (k == 0) {
-          reflFirst = refl;
-        } else {
-          Level lv;
-          lv.emission = cur.emission;
-          lv.diffuse = cur.diffuse;
-          lv.reflective = refl;
-          stack[nlev++] = lv; // every lane stores the same wave-uniform value
-        }
-        o = cur.pos;
-        d = nd;
-      }
-      const int depth = k + 1;
-      d3 term;
-      bool terminated;
-      if (depth >= P.maxDepth) { // Scene.cpp:128
-        term = mk(0, 0, 0);
-        terminated = true;
-      } else {
-        const HitKey key = intersect(o, d);
-        if (uniformBool(key.idx == kMiss)) { // Scene.cpp:131-133
-          term = ld3(P.env);
-          terminated = true;
-        } else {
-          cur = surfaceAt(key, o, d);
-          dirIn = d;
-          terminated = P.preview != 0; // Scene.cpp:137-138 (only reachable at depth 0)
-          term = cur.diffuse;
-        }
-      }
-      if (!terminated) {
-        if (depth == 0) {
-          first = cur;
-          dirFirst = d;
-        }
-        k = depth;
-        continue;
-      }
-      if (depth == 0) return term;
-      // fold the chain innermost-first: L_d = E_d + T_d * L_{d+1}
-      d3 L = term;
-      for (int i = nlev - 1; i >= 0; --i) {
-        const Level lv = stack[i];
-        L = uniformBool(lv.reflective) ? lv.emission + L : lv.emission + lv.diffuse * L;
-      }
-      result = result + (reflFirst ? first.emission + L : first.emission + first.diffuse * L);
-      if (++sub == nSub) return result * P.invFirstBounce;
-      cur = first;
-      dirIn = dirFirst;
-      k = 0;
-      nlev = 0;
-    }
-  }
 };
 
 // Bytes of dynamic LDS traceSequential needs (also computed on the host for the launch).
@@ -735,8 +668,6 @@ __global__ __launch_bounds__(64 * WAVES) void traceSequential(
   ctx.words = 0;
   ctx.rays = 0;
   ctx.parity = 0;
-  ctx.pfValid = false;
-  ctx.pf0 = ctx.pf1 = ctx.pf2 = 0;
   if (LDS_TABLES) {
     SphereRec *ls = reinterpret_cast<SphereRec *>(ldsRaw + off);
     double *lt = reinterpret_cast<double *>(ls + p.nsph);
@@ -784,11 +715,7 @@ __global__ __launch_bounds__(64 * WAVES) void traceSequential(
     }
     d3 o, d;
     cameraRay(p.cam, px, py, r0, r1, r2, r3, o, d);
-#if PTW_SEQ_SINGLE_LOOP
-    const d3 L = ctx.samplePath(o, d);
-#else
     const d3 L = radiance0(ctx, p, triShade, spheres, o, d);
-#endif
     if (threadIdx.x == 0) {
       myStage[i * 3 + 0] = L.x;
       myStage[i * 3 + 1] = L.y;
@@ -851,7 +778,11 @@ struct PixCtx {
     words += 2;
     return canonicalFromWords(w0, w1);
   }
-  __device__ __forceinline__ void prefetch3() {}
+  __device__ __forceinline__ bool scatterChain(const Surface &s, d3 dirIn, d3 &dirOut) {
+    double u, v, pd;
+    draw3(u, v, pd);
+    return scatter(*this, s, dirIn, u, v, pd, dirOut);
+  }
   __device__ __forceinline__ unsigned long long now() const { return 0; }
   __device__ __forceinline__ void addScatter(unsigned long long, double &) {}
   __device__ __forceinline__ void draw3(double &a, double &b, double &c) {
