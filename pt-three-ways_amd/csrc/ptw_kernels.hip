@@ -60,11 +60,19 @@ struct Surface {
   d3 pos;
   d3 normal;
   Basis basis;
-  double reflectivity;
+  double reflectivity;    // resolved value (eager paths)
   d3 emission;
   d3 diffuse;
   double coneAngle;
+  // inputs of Norm3::reflectance for paths that resolve the lobe lazily
+  double matReflectivity; // MaterialSpec::reflectivity (< 0 => Fresnel-ish)
+  double iorFrom, iorTo, iorRatio;
 };
+
+__device__ __forceinline__ double resolveReflectivity(const Surface &s, d3 dirIn) {
+  return s.matReflectivity < 0 ? reflectance(s.normal, dirIn, s.iorFrom, s.iorTo, s.iorRatio)
+                               : s.matReflectivity;
+}
 
 __device__ __forceinline__ d3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
 
@@ -142,11 +150,11 @@ __device__ __forceinline__ Surface makeSurface(const TraceParams &p, const TriSh
     ior = r.ior, invIor = r.invIor, reflectivity = r.reflectivity;
   }
   // Scene.cpp:140-146
-  const double iorFrom = inside ? ior : 1.0;
-  const double iorTo = inside ? 1.0 : ior;
-  const double iorRatio = inside ? ior : invIor; // ior / 1.0 == ior ; 1.0 / ior
-  s.reflectivity =
-      reflectivity < 0 ? reflectance(s.normal, d, iorFrom, iorTo, iorRatio) : reflectivity;
+  s.iorFrom = inside ? ior : 1.0;
+  s.iorTo = inside ? 1.0 : ior;
+  s.iorRatio = inside ? ior : invIor; // ior / 1.0 == ior ; 1.0 / ior
+  s.matReflectivity = reflectivity;
+  s.reflectivity = resolveReflectivity(s, d);
   return s;
 }
 
@@ -221,7 +229,15 @@ __device__ __forceinline__ d3 radianceChain(CTX &ctx, const TraceParams &p,
       L = ld3(p.env);
       break;
     }
-    const Surface s = ctx.surfaceAt(k, o, d);
+    if (depth + 1 >= p.maxDepth) {
+      // Last level: the child is radiance(depth + 1 >= maxDepth) = 0 (Scene.cpp:128), so this
+      // level returns E + 0 or E + D * 0 = E whatever the lobe; the new direction is never
+      // used.  Only the three draws it consumes matter to the stream.
+      ctx.skip3();
+      L = ctx.emissionAt(k);
+      break;
+    }
+    const Surface s = ctx.surfaceAt(k, o, d, false);
     // numUSamples == numVSamples == 1: (0 + xi) / 1.0 == xi exactly
     const unsigned long long tS0 = ctx.now();
     d3 nd;
@@ -537,6 +553,25 @@ struct SeqCtx {
 
   __device__ __forceinline__ bool branch(bool b) const { return uniformBool(b); }
 
+  __device__ __forceinline__ d3 emissionAt(const HitKey &k) const {
+    if (k.idx >= p->nsph) {
+      const double *r = tab.tri + static_cast<size_t>(k.idx - p->nsph) * kTriCompactDoubles;
+      return ld3(tab.mat + static_cast<size_t>(static_cast<uint32_t>(r[9])) * kMatDoubles);
+    }
+    return ld3(tab.sph[k.idx].emission);
+  }
+  // consume three draws without looking at them
+  __device__ __forceinline__ void skip3() {
+    if (pos + 3 <= kMtDoubles) {
+      pos += 3;
+      words += 6;
+    } else {
+      (void)draw();
+      (void)draw();
+      (void)draw();
+    }
+  }
+
   // The scatter of a single-sample level (depth >= 1): u = xi1, v = xi2, p = xi3 drawn in that
   // order (Scene.cpp:157-161).  When the three draws sit inside the current block, the diffuse
   // lobe takes its local direction from the precomputed table.
@@ -547,7 +582,7 @@ struct SeqCtx {
       const d3 local = mk(sh->hemi[q][0], sh->hemi[q][1], sh->hemi[q][2]);
       pos += 3;
       words += 6;
-      if (uniformBool(pd < s.reflectivity)) { // Scene.cpp:163-168
+      if (uniformBool(lobeIsReflective(s, dirIn, pd))) { // Scene.cpp:163-168
         dirOut = coneSample(reflect(s.normal, dirIn), s.coneAngle, sh->canon[q], sh->canon[q + 1]);
         return true;
       }
@@ -556,7 +591,23 @@ struct SeqCtx {
     }
     double u, v, pd;
     draw3(u, v, pd); // straddles a regeneration
-    return scatter(*this, s, dirIn, u, v, pd, dirOut);
+    Surface r = s;
+    r.reflectivity = resolveReflectivity(s, dirIn);
+    return scatter(*this, r, dirIn, u, v, pd, dirOut);
+  }
+
+  // `p < reflectivity` (Scene.cpp:143-146,163) without always evaluating Norm3::reflectance.
+  // For ior == 1 on both sides the reflectance is ((c - c') / (c + c'))^2 with c' = sqrt(1 - (1 -
+  // c^2)) differing from c = cos(theta_i) only by rounding: |c'^2 - c^2| <= 3e-16, so for
+  // c >= 1e-3 the value is below 2^-64, the spacing of the canonical draws - `p < reflectivity`
+  // can then only hold for p == 0.  Everything else takes the exact evaluation.
+  __device__ __forceinline__ bool lobeIsReflective(const Surface &s, d3 dirIn, double pd) const {
+    if (uniformBool(s.matReflectivity >= 0)) return pd < s.matReflectivity;
+    if (uniformBool(s.iorFrom == 1.0 && s.iorTo == 1.0)) {
+      const double cosThetaI = -dot(s.normal, dirIn);
+      if (uniformBool(cosThetaI >= 1e-3 && pd > 0.0)) return false;
+    }
+    return pd < reflectance(s.normal, dirIn, s.iorFrom, s.iorTo, s.iorRatio);
   }
 #if PTW_PROFILE_PHASES
   __device__ __forceinline__ unsigned long long now() const { return __builtin_amdgcn_s_memtime(); }
@@ -578,7 +629,7 @@ struct SeqCtx {
   __device__ __forceinline__ Level top(int level) const { return stack[level]; }
 
   // Surface at a hit from the shading tables (same values as makeSurface()).
-  __device__ __forceinline__ Surface surfaceAt(const HitKey &k, d3 o, d3 d) {
+  __device__ __forceinline__ Surface surfaceAt(const HitKey &k, d3 o, d3 d, bool eager = true) {
     PTW_T(tA);
     Surface s;
     s.pos = o + d * k.t;
@@ -610,11 +661,11 @@ struct SeqCtx {
       s.coneAngle = r.coneAngle;
       ior = r.ior, invIor = r.invIor, reflectivity = r.reflectivity;
     }
-    const double iorFrom = inside ? ior : 1.0;
-    const double iorTo = inside ? 1.0 : ior;
-    const double iorRatio = inside ? ior : invIor;
-    s.reflectivity =
-        reflectivity < 0 ? reflectance(s.normal, d, iorFrom, iorTo, iorRatio) : reflectivity;
+    s.iorFrom = inside ? ior : 1.0;
+    s.iorTo = inside ? 1.0 : ior;
+    s.iorRatio = inside ? ior : invIor;
+    s.matReflectivity = reflectivity;
+    s.reflectivity = eager ? resolveReflectivity(s, d) : 0.0;
 #if PTW_PROFILE_PHASES
     asm volatile("" : "+v"(s.reflectivity), "+v"(s.pos.x), "+v"(s.basis.y.z), "+v"(s.diffuse.x));
 #endif
@@ -763,8 +814,15 @@ struct PixCtx {
   const double *triGeom;
   const TriShade *triShade;
   const SphereRec *spheres;
-  __device__ __forceinline__ Surface surfaceAt(const HitKey &k, d3 o, d3 d) const {
+  __device__ __forceinline__ Surface surfaceAt(const HitKey &k, d3 o, d3 d, bool = true) const {
     return makeSurface(*p, triShade, spheres, k, o, d);
+  }
+  __device__ __forceinline__ d3 emissionAt(const HitKey &k) const {
+    return k.idx >= p->nsph ? ld3(triShade[k.idx - p->nsph].emission) : ld3(spheres[k.idx].emission);
+  }
+  __device__ __forceinline__ void skip3() {
+    for (int i = 0; i < 6; ++i) (void)rng.next();
+    words += 6;
   }
   Sfc32 rng;
   unsigned words;
