@@ -620,11 +620,16 @@ struct SeqCtx {
   __device__ __forceinline__ void addScatter(unsigned long long, double &) {}
 #endif
   __device__ __forceinline__ void push(int level, d3 e, d3 dif, bool refl) {
-    Level lv;
-    lv.emission = e;
-    lv.diffuse = dif;
-    lv.reflective = refl;
-    stack[level] = lv; // every lane stores the same wave-uniform value
+    // One lane stores (64 lanes writing one address would serialise in the LDS); every lane
+    // reads it back later.  The address is the same for the store and the loads, so the
+    // compiler keeps them ordered.
+    if ((tid & 63) == 0) {
+      Level lv;
+      lv.emission = e;
+      lv.diffuse = dif;
+      lv.reflective = refl;
+      stack[level] = lv;
+    }
   }
   __device__ __forceinline__ Level top(int level) const { return stack[level]; }
 
@@ -638,7 +643,15 @@ struct SeqCtx {
     if (k.idx >= p->nsph) {
       const double *r = tab.tri + static_cast<size_t>(k.idx - p->nsph) * kTriCompactDoubles;
       const bool backfacing = k.det < kEpsilon;
-      const d3 n = ld3(r), bx = ld3(r + 3);
+#if PTW_PROFILE_PHASES
+      PTW_T(tL0);
+#endif
+      d3 n = ld3(r), bx = ld3(r + 3);
+#if PTW_PROFILE_PHASES
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n.x), "+v"(bx.x)::"memory");
+      PTW_T(tL1);
+      PTW_ACC(4, tL0, tL1);
+#endif
       s.normal = backfacing ? -n : n;
       s.basis.x = backfacing ? -bx : bx;
       s.basis.y = ld3(r + 6);
@@ -779,9 +792,9 @@ __global__ __launch_bounds__(64 * WAVES) void traceSequential(
   if (pass == 0 && threadIdx.x == 0) {
     const unsigned long long tEnd = __builtin_amdgcn_s_memtime();
     const double r = static_cast<double>(ctx.rays);
-    printf("PHASES rays=%llu total/ray=%.0f tests=%.0f reduce=%.0f surface=%.0f scatter=%.0f other=%.0f\n",
+    printf("PHASES rays=%llu total/ray=%.0f tests=%.0f reduce=%.0f surface=%.0f (lds1=%.0f) scatter=%.0f other=%.0f\n",
            ctx.rays, (tEnd - tStart) / r, ctx.prof[0] / r, ctx.prof[1] / r, ctx.prof[2] / r,
-           ctx.prof[3] / r,
+           ctx.prof[4] / r, ctx.prof[3] / r,
            ((tEnd - tStart) - ctx.prof[0] - ctx.prof[1] - ctx.prof[2] - ctx.prof[3]) / r);
   }
 #endif

@@ -14,4 +14,4 @@ rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc3 -o pmc3 -- $CMD > $OUT/pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc4 -o pmc4 -- $CMD > $OUT/pmc4.log 2>&1
 find $OUT -name "*.csv" | head -30
 for f in $(find $OUT/trace -name "*kernel_stats.csv"); do echo "== $f"; head -12 $f; done
-tail -3 $OUT/*.log
+tail -n 3 $OUT/trace.log

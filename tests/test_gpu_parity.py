@@ -249,3 +249,36 @@ def test_row_window_perpixel(pkg, ob):
                         row_begin=5, row_end=9)
     assert np.array_equal(part[5:9], full[5:9]) and not part[:5].any() and not part[9:].any()
     assert np.all(cnt[5:9] == 3) and not cnt[:5].any() and not cnt[9:].any()
+
+
+# ---- every kernel variant: random triangle/sphere soups sized to hit each <SLOTS, WAVES> -----
+def _soup(pkg, ntri, nsph, seed):
+    rng = np.random.default_rng(seed)
+    scene = pkg.Scene()
+    mats = [pkg.material("diffuse", rng.uniform(0.2, 0.9, 3)),
+            pkg.material("light", rng.uniform(0.5, 3.0, 3)),
+            pkg.material("glossy", rng.uniform(0.2, 0.9, 3), 1.3, 20.0),
+            pkg.material("reflective", rng.uniform(0.2, 0.9, 3), 0.5, 4.0),
+            pkg.material("specular", rng.uniform(0.2, 0.9, 3), 1.0)]
+    for i in range(ntri):
+        c = rng.uniform(-3, 3, 3)
+        v = c + rng.uniform(-0.6, 0.6, (3, 3))
+        scene.add_triangle(v[0], v[1], v[2], mats[i % len(mats)])
+    for i in range(nsph):
+        scene.add_sphere(rng.uniform(-3, 3, 3), rng.uniform(0.05, 0.4), mats[(i + 2) % len(mats)])
+    scene.add_sphere((0, 0, 0), 12.0, mats[0])  # enclosing shell: long paths
+    scene.set_environment_colour((0.1, 0.2, 0.3))
+    cam = pkg.set_focus(pkg.look_at((0, 0.5, 7), (0, 0, 0), (0, 1, 0), 10, 8, 45.0), (0, 0, 0), 0.02)
+    return scene, cam
+
+
+@pytest.mark.parametrize("ntri,nsph", [(50, 3), (100, 0), (200, 70), (400, 2), (900, 5), (1800, 1),
+                                       (3500, 300), (5000, 9)])
+@pytest.mark.parametrize("policy", [0, 1])
+def test_kernel_variants_on_random_soups(pkg, ob, ntri, nsph, policy):
+    scene, cam = _soup(pkg, ntri, nsph, seed=ntri + nsph)
+    params = pkg.default_params(width=10, height=8, samples_per_pixel=2, seed=3, rng_policy=policy)
+    ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(scene.view(), cam, params, threads=2)
+    rgb, cnt, words = gpu_render_with_words(pkg, scene, cam, params)
+    assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words)
+    assert rel_err(rgb, ref_rgb) < TOL
