@@ -1,1 +1,1 @@
-timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "soups" 2>&1 | tail -12
+timeout 900 python -m pytest tests/test_gpu_cli.py -x -q -m gpu 2>&1 | tail -12

@@ -1,0 +1,65 @@
+"""GPU: the command-line host (pt_three_ways_hip, raw_to_png_hip) end to end - the reference's
+seed test (test/seed_tests.sh) and its raw_to_png merge flow, against the C-ABI results."""
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def run_cli(pkg, args, cwd):
+    exe = pkg.LIB_PATH.parent / "pt_three_ways_hip"
+    proc = subprocess.run([str(exe)] + args, cwd=cwd, capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    return proc.stdout
+
+
+def test_seed_tests_sh_equivalent(pkg, tmp_path):
+    from conftest import ROOT
+    base = ["--width", "16", "--height", "16", "--max-cpus", "1", "--spp", "16", "--scene", "cornell",
+            "--way", "hip", "--raw", "--save-every", "0"]
+    out = run_cli(pkg, base + ["--seed", "1", str(tmp_path / "a.raw")], ROOT)
+    assert "Scene contains 38 triangles and 1 spheres." in out
+    assert "Total samples: 4096" in out and "Samples/ms:" in out
+    run_cli(pkg, base + ["--seed", "1", str(tmp_path / "b.raw")], ROOT)
+    run_cli(pkg, base + ["--seed", "2", str(tmp_path / "c.raw")], ROOT)
+    a, b, c = [(tmp_path / f"{n}.raw").read_bytes() for n in "abc"]
+    assert a == b and a != c and len(a) == 16 + 256 * 28
+    # the CLI result is the C-ABI result
+    scene = pkg.Scene()
+    cam = scene.build_named("cornell", 16, 16)
+    rgb, cnt = pkg.render(scene, cam, pkg.default_params(width=16, height=16, samples_per_pixel=16, seed=1))
+    lrgb, lcnt = pkg.raw_load(tmp_path / "a.raw")
+    assert np.array_equal(lrgb, rgb) and np.array_equal(lcnt, cnt)
+
+
+def test_chunked_save_every_and_png_and_merge(pkg, tmp_path):
+    from conftest import ROOT
+    # --save-every > 0 renders in pass chunks: same bytes as one shot
+    common = ["-w", "20", "-h", "12", "--spp", "9", "--seed", "5", "--scene", "single-sphere", "--raw"]
+    run_cli(pkg, common + ["--save-every", "0", str(tmp_path / "one.raw")], ROOT)
+    run_cli(pkg, common + ["--save-every", "30", str(tmp_path / "chunks.raw")], ROOT)
+    assert (tmp_path / "one.raw").read_bytes() == (tmp_path / "chunks.raw").read_bytes()
+    # PNG output + raw_to_png merge of two seeds
+    run_cli(pkg, ["-w", "20", "-h", "12", "--spp", "4", "--seed", "6", "--scene", "single-sphere", "--raw",
+                  "--save-every", "0", str(tmp_path / "two.raw")], ROOT)
+    merge = subprocess.run([str(pkg.LIB_PATH.parent / "raw_to_png_hip"), str(tmp_path / "m.png"),
+                            str(tmp_path / "one.raw"), str(tmp_path / "two.raw")],
+                           capture_output=True, text=True, timeout=60)
+    assert merge.returncode == 0 and "with 3120 samples (13.0 per pixel)" in merge.stdout
+    assert (tmp_path / "m.png").read_bytes()[:8] == b"\x89PNG\r\n\x1a\n"
+    out = run_cli(pkg, ["-w", "8", "-h", "8", "--spp", "2", "--seed", "7", "--scene", "ce", "--save-every", "0",
+                        str(tmp_path / "ce.png")], ROOT)
+    assert "Scene contains 3442 triangles and 3 spheres." in out
+
+
+def test_cli_errors(pkg, tmp_path):
+    from conftest import ROOT
+    exe = str(pkg.LIB_PATH.parent / "pt_three_ways_hip")
+    for args, text in [(["--way", "dod", "x.png"], "Unknown way dod"),
+                       (["--scene", "nope", "--seed", "1", "x.png"], "Unknown scene nope"),
+                       ([], "Missing output filename."),
+                       (["--bogus", "x.png"], "Unrecognised token: --bogus")]:
+        proc = subprocess.run([exe] + args, cwd=ROOT, capture_output=True, text=True, timeout=60)
+        assert proc.returncode == 1 and text in (proc.stdout + proc.stderr)
