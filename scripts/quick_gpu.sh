@@ -1,1 +1,1 @@
-timeout 900 python -m pytest tests/test_gpu_cli.py -x -q -m gpu 2>&1 | tail -12
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -3
