@@ -243,7 +243,7 @@ __device__ __forceinline__ d3 radianceChain(CTX &ctx, const TraceParams &p,
     d3 nd;
     const bool refl = ctx.scatterChain(s, d, nd);
     ctx.addScatter(tS0, nd.x);
-    ctx.push(nlev++, s.emission, s.diffuse, refl);
+    ctx.push(nlev++, s.emission, s.diffuse, refl, k.idx);
     o = s.pos;
     d = nd;
   }
@@ -619,7 +619,7 @@ struct SeqCtx {
   __device__ __forceinline__ unsigned long long now() const { return 0; }
   __device__ __forceinline__ void addScatter(unsigned long long, double &) {}
 #endif
-  __device__ __forceinline__ void push(int level, d3 e, d3 dif, bool refl) {
+  __device__ __forceinline__ void push(int level, d3 e, d3 dif, bool refl, uint32_t) {
     // One lane stores (64 lanes writing one address would serialise in the LDS); every lane
     // reads it back later.  The address is the same for the store and the loads, so the
     // compiler keeps them ordered.
@@ -840,7 +840,7 @@ struct PixCtx {
   Sfc32 rng;
   unsigned words;
   unsigned long long rays;
-  Level *stack; // this lane's slice of the block's LDS stack, stride = blockDim.x
+  uint32_t *stack; // this lane's slice of the block's LDS stack, stride = blockDim.x
 
   __device__ __forceinline__ bool branch(bool b) const { return b; }
   __device__ __forceinline__ double draw() {
@@ -861,14 +861,26 @@ struct PixCtx {
     b = draw();
     c = draw();
   }
-  __device__ __forceinline__ void push(int level, d3 e, d3 dif, bool refl) {
-    Level lv;
-    lv.emission = e;
-    lv.diffuse = dif;
-    lv.reflective = refl;
-    stack[level * blockDim.x] = lv;
+  // The (E, T) stack holds one word per level: the combined primitive index of the hit and the
+  // lobe flag; emission and diffuse are re-read from the (cache-resident) records at fold time.
+  __device__ __forceinline__ void push(int level, d3, d3, bool refl, uint32_t idx) {
+    stack[level * blockDim.x] = idx | (refl ? 0x80000000u : 0u);
   }
-  __device__ __forceinline__ Level top(int level) const { return stack[level * blockDim.x]; }
+  __device__ __forceinline__ Level top(int level) const {
+    const uint32_t w = stack[level * blockDim.x];
+    const uint32_t idx = w & 0x7fffffffu;
+    Level lv;
+    lv.reflective = (w >> 31) != 0;
+    if (idx >= p->nsph) {
+      const TriShade &r = triShade[idx - p->nsph];
+      lv.emission = ld3(r.emission);
+      lv.diffuse = ld3(r.diffuse);
+    } else {
+      lv.emission = ld3(spheres[idx].emission);
+      lv.diffuse = ld3(spheres[idx].diffuse);
+    }
+    return lv;
+  }
 
   __device__ __forceinline__ HitKey intersect(d3 o, d3 d) {
     rays++;
@@ -920,12 +932,15 @@ struct PixCtx {
 
 constexpr int kPixBlock = 256;
 
-__global__ __launch_bounds__(kPixBlock) void tracePerPixel(
+// 4 waves per SIMD: the (E, T) stack is one word per level, so registers are what limits
+// residency; capping them at 128 costs a few spills outside the triangle loop and pays back in
+// latency hiding.
+__global__ __launch_bounds__(kPixBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void tracePerPixel(
     const TraceParams p, const double *__restrict__ triGeom,
     const TriShade *__restrict__ triShade, const SphereRec *__restrict__ spheres,
     double *__restrict__ stage, uint32_t *__restrict__ words,
     unsigned long long *__restrict__ rayCounters) {
-  extern __shared__ Level pixStacks[]; // [maxDepth][blockDim.x]
+  extern __shared__ uint32_t pixStacks[]; // [maxDepth][blockDim.x]
   const uint64_t gid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
   if (gid >= total) return;
@@ -973,7 +988,7 @@ __global__ __launch_bounds__(kPixBlock) void tracePerPixel(
 // -----------------------------------------------------------------------------------------
 constexpr int kPix2Block = 256;
 
-__global__ __launch_bounds__(kPix2Block) void tracePerPixelPersistent(
+__global__ __launch_bounds__(kPix2Block) __attribute__((amdgpu_waves_per_eu(4, 4))) void tracePerPixelPersistent(
     const TraceParams p, const double *__restrict__ triGeom,
     const SphereRec *__restrict__ spheres, const double *__restrict__ triCompact,
     const double *__restrict__ matTable, double *__restrict__ stage, uint32_t *__restrict__ words,
@@ -1160,12 +1175,9 @@ __global__ __launch_bounds__(kPix2Block) void tracePerPixelPersistent(
                 nd = hemisphereSample(s.basis, u, v);
                 refl = false;
               }
-              // push (emission, diffuse) by value: two 3-vectors per level in LDS
-              double *lv = reinterpret_cast<double *>(pixLevels) +
-                           (static_cast<size_t>(nlev) * blockDim.x + threadIdx.x) * 7;
-              lv[0] = s.emission.x, lv[1] = s.emission.y, lv[2] = s.emission.z;
-              lv[3] = s.diffuse.x, lv[4] = s.diffuse.y, lv[5] = s.diffuse.z;
-              lv[6] = refl ? 1.0 : 0.0;
+              // push: one word per level (combined primitive index + lobe flag)
+              pixLevels[static_cast<size_t>(nlev) * blockDim.x + threadIdx.x] =
+                  key.idx | (refl ? 0x80000000u : 0u);
               nlev++;
               o = s.pos;
               d = nd;
@@ -1186,10 +1198,16 @@ __global__ __launch_bounds__(kPix2Block) void tracePerPixelPersistent(
           // fold innermost-first
           d3 L = term;
           for (int i = nlev - 1; i >= 0; --i) {
-            const double *lv = reinterpret_cast<const double *>(pixLevels) +
-                               (static_cast<size_t>(i) * blockDim.x + threadIdx.x) * 7;
-            const d3 e = mk(lv[0], lv[1], lv[2]), df = mk(lv[3], lv[4], lv[5]);
-            L = lv[6] != 0.0 ? e + L : e + df * L;
+            const uint32_t w = pixLevels[static_cast<size_t>(i) * blockDim.x + threadIdx.x];
+            const uint32_t idx = w & 0x7fffffffu;
+            const double *m =
+                idx >= nsph
+                    ? matTable + static_cast<size_t>(static_cast<uint32_t>(
+                                     triCompact[static_cast<size_t>(idx - nsph) * kTriCompactDoubles + 9])) *
+                                     kMatDoubles
+                    : spheres[idx].emission; // SphereRec: emission[3] then diffuse[3]
+            const d3 e = ld3(m), df = ld3(m + 3);
+            L = (w >> 31) ? e + L : e + df * L;
           }
           result = result + (reflFirst ? first.emission + L : first.emission + first.diffuse * L);
           if (++sub == nSub) {
@@ -1388,7 +1406,7 @@ hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipS
     const uint64_t needed = (total + kPix2Block - 1) / kPix2Block;
     if (blocks > needed) blocks = needed;
     const int levels = p.maxDepth > 1 ? p.maxDepth - 1 : 1;
-    const size_t lds = static_cast<size_t>(levels) * kPix2Block * 7 * sizeof(double);
+    const size_t lds = static_cast<size_t>(levels) * kPix2Block * sizeof(uint32_t);
     hipLaunchKernelGGL(tracePerPixelPersistent, dim3(static_cast<uint32_t>(blocks)),
                        dim3(kPix2Block), lds, stream, p, b.triGeom, b.spheres, b.triCompact,
                        b.matTable, b.stage, b.words, b.rays);
@@ -1397,7 +1415,7 @@ hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipS
   const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
   const uint32_t blocks = static_cast<uint32_t>((total + kPixBlock - 1) / kPixBlock);
   const int levels = p.maxDepth > 1 ? p.maxDepth - 1 : 1;
-  const size_t lds = static_cast<size_t>(levels) * kPixBlock * sizeof(Level);
+  const size_t lds = static_cast<size_t>(levels) * kPixBlock * sizeof(uint32_t);
   hipLaunchKernelGGL(tracePerPixel, dim3(blocks), dim3(kPixBlock), lds, stream, p, b.triGeom,
                      b.triShade, b.spheres, b.stage, b.words, b.rays);
   return hipGetLastError();
