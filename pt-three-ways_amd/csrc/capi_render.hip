@@ -70,6 +70,7 @@ struct ptw_context {
   uint32_t nmat = 0;
   DeviceArray<uint32_t> mtState, mtPos;
   DeviceArray<double> stage;
+  DeviceArray<unsigned long long> sampleQueue; // work counter of the persistent kernel
   DeviceArray<unsigned long long> rays; // per-pass intersect() counters, accumulated
   uint64_t rayCarry = 0;                // counts folded in when `rays` had to grow
   std::vector<uint32_t> hostSeedStates; // kept alive for the async upload
@@ -218,6 +219,8 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   b.stage = ctx.stage.ptr;
   b.words = dWords;
   b.rays = ctx.rays.ptr;
+  ctx.sampleQueue.reserve(1);
+  b.sampleQueue = ctx.sampleQueue.ptr;
 
   auto timedLaunch = [&](bool trace, auto &&launch) {
     if (!ctx.statsEnabled) {

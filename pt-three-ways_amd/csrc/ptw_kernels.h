@@ -38,6 +38,7 @@ struct TraceBuffers {
   double *stage;             // [npass][pixCount][3] this band's per-pass radiance
   uint32_t *words;           // optional [npass][npix]
   unsigned long long *rays;  // optional [npass] intersect() call counters
+  unsigned long long *sampleQueue; // one word: next sample index (tracePerPixelPersistent)
 };
 
 // SEQUENTIAL policy: one workgroup per pass walks the band's pixels in row-major order.

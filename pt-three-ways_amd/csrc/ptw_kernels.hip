@@ -992,12 +992,14 @@ __global__ __launch_bounds__(kPix2Block) __attribute__((amdgpu_waves_per_eu(4, 4
     const TraceParams p, const double *__restrict__ triGeom,
     const SphereRec *__restrict__ spheres, const double *__restrict__ triCompact,
     const double *__restrict__ matTable, double *__restrict__ stage, uint32_t *__restrict__ words,
-    unsigned long long *__restrict__ rayCounters) {
+    unsigned long long *__restrict__ rayCounters, unsigned long long *__restrict__ sampleQueue) {
   extern __shared__ uint32_t pixLevels[]; // [maxDepth][blockDim.x]: (material << 1) | reflective
   const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
-  const uint64_t lanes = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-  uint64_t sample = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  uint32_t *myLevels = pixLevels + threadIdx.x;
+  // Samples are handed out through one device-wide counter: a lane that finishes a sample takes
+  // the next index (the compiler folds the lanes of a wave into one atomic).  A static
+  // lane -> sample map would pin a lane to one pixel across passes, and pixels differ in cost
+  // by 60x (background vs. many-bounce paths).
+  uint64_t sample = atomicAdd(sampleQueue, 1ull);
   const uint32_t nsph = p.nsph, ntri = p.ntri;
   const int nSub = p.fbU * p.fbV;
 
@@ -1047,7 +1049,7 @@ __global__ __launch_bounds__(kPix2Block) __attribute__((amdgpu_waves_per_eu(4, 4
     double *out = stage + (static_cast<size_t>(pass) * p.pixCount + pixIdx) * 3;
     out[0] = L.x, out[1] = L.y, out[2] = L.z;
     if (words) words[static_cast<size_t>(pass) * p.npix + p.pixBegin + pixIdx] = nwords;
-    sample += lanes;
+    sample = atomicAdd(sampleQueue, 1ull);
     active = sample < total;
   };
 
@@ -1407,9 +1409,11 @@ hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipS
     if (blocks > needed) blocks = needed;
     const int levels = p.maxDepth > 1 ? p.maxDepth - 1 : 1;
     const size_t lds = static_cast<size_t>(levels) * kPix2Block * sizeof(uint32_t);
+    hipError_t e = hipMemsetAsync(b.sampleQueue, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tracePerPixelPersistent, dim3(static_cast<uint32_t>(blocks)),
                        dim3(kPix2Block), lds, stream, p, b.triGeom, b.spheres, b.triCompact,
-                       b.matTable, b.stage, b.words, b.rays);
+                       b.matTable, b.stage, b.words, b.rays, b.sampleQueue);
     return hipGetLastError();
   }
   const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
