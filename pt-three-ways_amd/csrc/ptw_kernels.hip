@@ -305,6 +305,14 @@ struct PartialHit {
   uint32_t pad;
 };
 
+// Master -> worker request of the multi-wave sequential kernel.
+constexpr uint32_t kCmdTrace = 1, kCmdExit = 2;
+struct SeqCommand {
+  double o[3], d[3];
+  uint32_t op;
+  uint32_t pad;
+};
+
 // std::mt19937 regeneration (the "twist") + tempering + generate_canonical for all 312
 // doubles, by the 64 lanes of one wave.  Chunks of 64 consecutive k are processed in order;
 // inside a chunk every lane reads its inputs, waveSync(), then writes, waveSync() - the
@@ -363,7 +371,10 @@ struct SeqTables {
 
 template <int SLOTS, int WAVES, bool LDS_TABLES>
 struct SeqCtx {
-  static constexpr int kThreads = 64 * WAVES;
+  // WAVES == 1: one wave does everything.  WAVES > 1: WAVES worker waves hold the primitives
+  // and one extra master wave (wave 0, no resident primitives) runs the path logic.
+  static constexpr int kThreads = 64 * WAVES;                        // lanes that hold primitives
+  static constexpr int kBlock = WAVES == 1 ? 64 : 64 * (WAVES + 1);  // workgroup size
 
   // per-lane resident triangles (SoA in registers)
   double v0x[SLOTS], v0y[SLOTS], v0z[SLOTS];
@@ -379,8 +390,9 @@ struct SeqCtx {
   SeqTables tab;
   SeqShared *sh;
   Level *stack;          // this wave's private radiance stack in LDS
-  PartialHit *partials;  // [2][WAVES] cross-wave exchange (WAVES > 1)
-  int tid;
+  PartialHit *partials;  // [WAVES] cross-wave exchange (WAVES > 1)
+  SeqCommand *cmd;       // master -> workers (WAVES > 1)
+  int tid;               // index among the primitive-holding lanes (workers); master: lane id
   int pos;               // next canonical double in sh->canon (wave-uniform)
   unsigned words;        // RNG words consumed by the current sample
   unsigned long long rays;
@@ -393,17 +405,15 @@ struct SeqCtx {
     const uint32_t ntri = p->ntri;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
+      // Branch-free on purpose: with an if/else the compiler sinks the two stores into one with a
+      // runtime slot index, which sends the slot arrays to scratch memory.  An unused slot gets a
+      // degenerate triangle (det == 0 -> always skipped); triGeom holds at least one record.
       const uint32_t k = static_cast<uint32_t>(tid) * SLOTS + s;
-      if (k < ntri) {
-        const double *g = triGeom + 9 * static_cast<size_t>(k);
-        v0x[s] = g[0], v0y[s] = g[1], v0z[s] = g[2];
-        e1x[s] = g[3], e1y[s] = g[4], e1z[s] = g[5];
-        e2x[s] = g[6], e2y[s] = g[7], e2z[s] = g[8];
-      } else { // degenerate: det == 0 -> always skipped
-        v0x[s] = v0y[s] = v0z[s] = 0;
-        e1x[s] = e1y[s] = e1z[s] = 0;
-        e2x[s] = e2y[s] = e2z[s] = 0;
-      }
+      const bool valid = k < ntri;
+      const double *g = triGeom + 9 * static_cast<size_t>(valid ? k : 0u);
+      v0x[s] = valid ? g[0] : 0.0, v0y[s] = valid ? g[1] : 0.0, v0z[s] = valid ? g[2] : 0.0;
+      e1x[s] = valid ? g[3] : 0.0, e1y[s] = valid ? g[4] : 0.0, e1z[s] = valid ? g[5] : 0.0;
+      e2x[s] = valid ? g[6] : 0.0, e2y[s] = valid ? g[7] : 0.0, e2z[s] = valid ? g[8] : 0.0;
     }
     hasSphere = static_cast<uint32_t>(tid) < p->nsph;
     if (hasSphere) {
@@ -414,19 +424,17 @@ struct SeqCtx {
     }
   }
 
-  __device__ __forceinline__ void regenerate() {
-    if (WAVES > 1) __syncthreads();
-    if (tid < 64) mtRegenerateWave(sh, tid);
-    if (WAVES > 1) __syncthreads();
-  }
+  // Only the master wave draws random numbers, so it regenerates on its own.
+  __device__ __forceinline__ void regenerate() { mtRegenerateWave(sh, threadIdx.x & 63); }
 
   // Rebuild canon[] from the current raw state without twisting (state resumed mid-block).
   __device__ __forceinline__ void rebuildCanon() {
-    if (tid < 64) {
-      for (int i = tid; i < kMtDoubles; i += 64)
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x;
+      for (int i = lane; i < kMtDoubles; i += 64)
         sh->canon[i] = canonicalFromWords(mtTemper(sh->mt[2 * i]), mtTemper(sh->mt[2 * i + 1]));
       waveSync();
-      fillHemiTable(sh, tid);
+      fillHemiTable(sh, lane);
     }
     __syncthreads();
   }
@@ -469,9 +477,9 @@ struct SeqCtx {
     }
   }
 
-  // Scene::intersect, Scene.cpp:115-122, cooperatively.
-  __device__ __forceinline__ HitKey intersect(d3 o, d3 d) {
-    rays++;
+  // This wave's part of Scene::intersect (Scene.cpp:115-122): its lanes' resident primitives
+  // against the ray, then the wave-level nearest hit with the reference's tie-break.
+  __device__ __forceinline__ HitKey localNearest(d3 o, d3 d) {
     PTW_T(tA);
     double bestT = kInf, bestDet = 0;
     uint32_t bestIdx = kMiss;
@@ -521,34 +529,80 @@ struct SeqCtx {
       key.idx = imin;
       key.det = readLane(bestDet, __builtin_ctzll(owner));
     }
-    if (WAVES > 1) {
-      PartialHit *slot = partials + (parity & 1u) * WAVES;
-      parity++;
-      if ((tid & 63) == 0) {
-        PartialHit ph;
-        ph.t = key.t, ph.det = key.det, ph.idx = key.idx, ph.pad = 0;
-        slot[tid >> 6] = ph;
-      }
-      __syncthreads();
-      HitKey best;
-      best.t = kInf, best.idx = kMiss, best.det = 0;
-#pragma unroll
-      for (int w = 0; w < WAVES; ++w) {
-        const PartialHit ph = slot[w];
-        if (ph.t < best.t || (ph.t == best.t && ph.idx < best.idx)) {
-          best.t = ph.t, best.idx = ph.idx, best.det = ph.det;
-        }
-      }
-      key.t = readFirstLane(best.t);
-      key.det = readFirstLane(best.det);
-      key.idx = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(best.idx)));
-    }
 #if PTW_PROFILE_PHASES
     asm volatile("" : "+v"(key.t));
 #endif
     PTW_T(tC);
     PTW_ACC(1, tB, tC);
     return key;
+  }
+
+  // Scene::intersect for the whole workgroup.  WAVES == 1: the wave's own result.  WAVES > 1:
+  // wave 0 (the master, the only wave that runs the path logic) publishes the ray, every wave
+  // searches its resident primitives, the partial results meet in LDS.  The worker waves sit in
+  // workerLoop() and do nothing but this - while the master shades, their SIMDs are free for
+  // the waves of other passes.
+  __device__ __forceinline__ HitKey intersect(d3 o, d3 d) {
+    rays++;
+    if (WAVES == 1) return localNearest(o, d);
+    if (threadIdx.x == 0) {
+      cmd->o[0] = o.x, cmd->o[1] = o.y, cmd->o[2] = o.z;
+      cmd->d[0] = d.x, cmd->d[1] = d.y, cmd->d[2] = d.z;
+      cmd->op = kCmdTrace;
+    }
+    __syncthreads(); // B1: ray visible to the workers
+    __syncthreads(); // B2: partial results visible
+    HitKey best;
+    best.t = kInf, best.idx = kMiss, best.det = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      const PartialHit ph = partials[w];
+      if (ph.t < best.t || (ph.t == best.t && ph.idx < best.idx)) {
+        best.t = ph.t, best.idx = ph.idx, best.det = ph.det;
+      }
+    }
+    HitKey key;
+    key.t = readFirstLane(best.t);
+    key.det = readFirstLane(best.det);
+    key.idx = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(best.idx)));
+    return key;
+  }
+
+  // Worker waves (WAVES > 1, wave != 0): serve nearest-hit requests until told to stop.
+  __device__ __forceinline__ void workerLoop() {
+#if PTW_PROFILE_PHASES
+    for (int i = 0; i < 8; ++i) prof[i] = 0;
+    unsigned long long nreq = 0;
+    const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+#endif
+    for (;;) {
+      __syncthreads(); // B1
+      if (cmd->op == kCmdExit) break;
+      const d3 o = mk(cmd->o[0], cmd->o[1], cmd->o[2]);
+      const d3 d = mk(cmd->d[0], cmd->d[1], cmd->d[2]);
+      const HitKey mine = localNearest(o, d);
+      if ((tid & 63) == 0) {
+        PartialHit ph;
+        ph.t = mine.t, ph.det = mine.det, ph.idx = mine.idx, ph.pad = 0;
+        partials[tid >> 6] = ph;
+      }
+      __syncthreads(); // B2
+#if PTW_PROFILE_PHASES
+      nreq++;
+#endif
+    }
+#if PTW_PROFILE_PHASES
+    if (blockIdx.x == 0 && tid == 0) {
+      const unsigned long long w1 = __builtin_amdgcn_s_memtime();
+      printf("WORKER requests=%llu total/req=%.0f tests=%.0f reduce=%.0f\n", nreq,
+             (double)(w1 - w0) / nreq, (double)prof[0] / nreq, (double)prof[1] / nreq);
+    }
+#endif
+  }
+  __device__ __forceinline__ void stopWorkers() {
+    if (WAVES == 1) return;
+    if (threadIdx.x == 0) cmd->op = kCmdExit;
+    __syncthreads(); // pairs with the workers' B1
   }
 
   __device__ __forceinline__ bool branch(bool b) const { return uniformBool(b); }
@@ -704,7 +758,7 @@ __host__ __device__ inline size_t seqLdsBytes(int waves, int maxDepth, bool ldsT
 }
 
 template <int SLOTS, int WAVES, bool LDS_TABLES>
-__global__ __launch_bounds__(64 * WAVES) void traceSequential(
+__global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + 1)) void traceSequential(
     const TraceParams p, const double *__restrict__ triGeom,
     const TriShade *__restrict__ triShade, const SphereRec *__restrict__ spheres,
     const double *__restrict__ triCompact, const double *__restrict__ matTable,
@@ -726,9 +780,12 @@ __global__ __launch_bounds__(64 * WAVES) void traceSequential(
   ctx.triGeom = triGeom;
   ctx.spheresGlobal = spheres;
   ctx.sh = &sh;
-  ctx.tid = threadIdx.x;
-  ctx.stack = stacks + (threadIdx.x >> 6) * depthSlots;
+  constexpr int kBlock = SeqCtx<SLOTS, WAVES, LDS_TABLES>::kBlock;
+  const bool isWorker = WAVES > 1 && threadIdx.x >= 64;
+  ctx.tid = WAVES == 1 ? threadIdx.x : (isWorker ? threadIdx.x - 64 : threadIdx.x);
+  ctx.stack = stacks; // only the master wave uses the radiance stack
   ctx.partials = partials;
+  ctx.cmd = reinterpret_cast<SeqCommand *>(partials + WAVES); // 56 B in the unused second half
   ctx.words = 0;
   ctx.rays = 0;
   ctx.parity = 0;
@@ -738,9 +795,9 @@ __global__ __launch_bounds__(64 * WAVES) void traceSequential(
     double *lm = lt + static_cast<size_t>(p.ntri) * kTriCompactDoubles;
     const double *gs = reinterpret_cast<const double *>(spheres);
     double *lsd = reinterpret_cast<double *>(ls);
-    for (uint32_t i = threadIdx.x; i < p.nsph * (sizeof(SphereRec) / 8); i += 64 * WAVES) lsd[i] = gs[i];
-    for (uint32_t i = threadIdx.x; i < p.ntri * kTriCompactDoubles; i += 64 * WAVES) lt[i] = triCompact[i];
-    for (uint32_t i = threadIdx.x; i < p.nmat * kMatDoubles; i += 64 * WAVES) lm[i] = matTable[i];
+    for (uint32_t i = threadIdx.x; i < p.nsph * (sizeof(SphereRec) / 8); i += kBlock) lsd[i] = gs[i];
+    for (uint32_t i = threadIdx.x; i < p.ntri * kTriCompactDoubles; i += kBlock) lt[i] = triCompact[i];
+    for (uint32_t i = threadIdx.x; i < p.nmat * kMatDoubles; i += kBlock) lm[i] = matTable[i];
     ctx.tab.sph = ls;
     ctx.tab.tri = lt;
     ctx.tab.mat = lm;
@@ -749,15 +806,22 @@ __global__ __launch_bounds__(64 * WAVES) void traceSequential(
     ctx.tab.tri = triCompact;
     ctx.tab.mat = matTable;
   }
-  ctx.loadPrimitives();
+  if (WAVES == 1 || isWorker) {
+    ctx.loadPrimitives();
+  } else {
+    ctx.hasSphere = false;
+  }
 
   // resume this pass's generator
   uint32_t *myState = mtState + static_cast<size_t>(pass) * kMtWords;
-  for (int i = threadIdx.x; i < kMtWords; i += 64 * WAVES) sh.mt[i] = myState[i];
+  for (int i = threadIdx.x; i < kMtWords; i += kBlock) sh.mt[i] = myState[i];
   ctx.pos = __builtin_amdgcn_readfirstlane(static_cast<int>(mtPos[pass]));
   __syncthreads();
   if (ctx.pos < kMtDoubles) ctx.rebuildCanon();
 
+  if (isWorker) {
+    ctx.workerLoop();
+  } else {
   const int w = p.width;
   const bool lens = p.cam.aperture_radius != 0;
   double *myStage = stage + static_cast<size_t>(pass) * p.pixCount * 3;
@@ -798,11 +862,13 @@ __global__ __launch_bounds__(64 * WAVES) void traceSequential(
            ((tEnd - tStart) - ctx.prof[0] - ctx.prof[1] - ctx.prof[2] - ctx.prof[3]) / r);
   }
 #endif
+  ctx.stopWorkers();
+  } // master
   // park the generator for the next band
   __syncthreads();
-  for (int i = threadIdx.x; i < kMtWords; i += 64 * WAVES) myState[i] = sh.mt[i];
+  for (int i = threadIdx.x; i < kMtWords; i += kBlock) myState[i] = sh.mt[i];
   if (threadIdx.x == 0) {
-    mtPos[pass] = static_cast<uint32_t>(ctx.pos);
+    mtPos[pass] = static_cast<uint32_t>(ctx.pos); // thread 0 belongs to the master wave
     if (rayCounters) rayCounters[pass] += ctx.rays;
   }
 }
@@ -1364,7 +1430,8 @@ hipError_t launchSeq(const TraceParams &p, const TraceBuffers &b, hipStream_t st
     if (e != hipSuccess) return e;
     configured = lds;
   }
-  hipLaunchKernelGGL(kernel, dim3(p.npass), dim3(64 * WAVES), lds, stream, p, b.triGeom, b.triShade,
+  hipLaunchKernelGGL(kernel, dim3(p.npass), dim3(WAVES == 1 ? 64 : 64 * (WAVES + 1)), lds, stream, p,
+                     b.triGeom, b.triShade,
                      b.spheres, b.triCompact, b.matTable, b.mtState, b.mtPos, b.stage, b.words,
                      b.rays);
   return hipGetLastError();
@@ -1381,15 +1448,18 @@ hipError_t launchSeqAuto(const TraceParams &p, const TraceBuffers &b, hipStream_
 
 hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
   const uint32_t n = p.ntri;
-  // Smallest resident configuration that holds every triangle in VGPRs; 1 wave up to 128
-  // triangles, otherwise 4 waves (one per SIMD of a CU) with up to 16 slots per lane.
+  // Smallest configuration that keeps every triangle resident in VGPRs.  Up to 128 triangles
+  // one wave does everything.  Beyond that 7 worker waves + 1 master wave = 8 waves = 2 per SIMD
+  // of one CU (256 registers per lane each): SLOTS triangles per worker lane.
   if (n <= 64) return launchSeqAuto<1, 1>(p, b, stream);
   if (n <= 128) return launchSeqAuto<2, 1>(p, b, stream);
-  if (n <= 256) return launchSeqAuto<1, 4>(p, b, stream);
-  if (n <= 512) return launchSeqAuto<2, 4>(p, b, stream);
-  if (n <= 1024) return launchSeqAuto<4, 4>(p, b, stream);
-  if (n <= 2048) return launchSeqAuto<8, 4>(p, b, stream);
-  return launchSeqAuto<16, 4>(p, b, stream); // beyond 4096 the tail is streamed from memory
+  if (n <= 448) return launchSeqAuto<1, 7>(p, b, stream);
+  if (n <= 896) return launchSeqAuto<2, 7>(p, b, stream);
+  if (n <= 1344) return launchSeqAuto<3, 7>(p, b, stream);
+  if (n <= 1792) return launchSeqAuto<4, 7>(p, b, stream);
+  if (n <= 2688) return launchSeq<6, 7, false>(p, b, stream);
+  if (n <= 3584) return launchSeq<8, 7, false>(p, b, stream);
+  return launchSeq<12, 7, false>(p, b, stream); // beyond 5376 the tail is streamed from memory
 }
 
 hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {

@@ -1,6 +1,7 @@
 #include "precompute.h"
 #include "vec3.h"
 
+#include <algorithm>
 #include <cstring>
 #include <stdexcept>
 
@@ -22,7 +23,8 @@ void copyMaterial(const ptw_material &m, double emission[3], double diffuse[3], 
 DeviceSceneData precomputeScene(const ptw_scene_view &scene) {
   DeviceSceneData out;
   std::memcpy(out.environment, scene.environment, sizeof out.environment);
-  out.triGeom.resize(static_cast<size_t>(scene.num_triangles) * 9);
+  // at least one (degenerate) record so that device code may always read slot 0
+  out.triGeom.assign(std::max<size_t>(static_cast<size_t>(scene.num_triangles), 1) * 9, 0.0);
   out.triShade.resize(scene.num_triangles);
   out.spheres.resize(scene.num_spheres);
   out.triMaterial.assign(scene.tri_material, scene.tri_material + scene.num_triangles);
