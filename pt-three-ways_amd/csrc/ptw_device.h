@@ -224,8 +224,10 @@ __device__ __forceinline__ double readLane(double x, int lane) {
 __device__ __forceinline__ double readFirstLane(double x) {
   return mk64(__builtin_amdgcn_readfirstlane(lo32(x)), __builtin_amdgcn_readfirstlane(hi32(x)));
 }
+// A condition every active lane agrees on, as a scalar branch condition: the compare's lane
+// mask tested against zero (v_cmp -> s_cmp_lg_u64 -> s_cbranch), no VGPR round trip.
 __device__ __forceinline__ bool uniformBool(bool b) {
-  return __builtin_amdgcn_readfirstlane(static_cast<int>(b)) != 0;
+  return __builtin_amdgcn_ballot_w64(b) != 0;
 }
 
 // Orders this wave's LDS/global accesses for cross-LANE communication through memory.  The

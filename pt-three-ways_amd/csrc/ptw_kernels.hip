@@ -509,12 +509,29 @@ struct SeqCtx {
 #endif
     PTW_T(tB);
     PTW_ACC(0, tA, tB);
-    unsigned tHi, tLo;
-    const double tmin = waveMinPositive(bestT, tHi, tLo);
     HitKey key;
-    if (tHi == 0x7ff00000u) { // +inf: no lane has a hit
+    // Most rays leave at most two lanes with a candidate (the line through a closed scene crosses
+    // few primitives on its positive side): pick the nearer of them with scalar code instead of
+    // a 64-lane reduction.
+    const unsigned long long cands = __builtin_amdgcn_ballot_w64(bestIdx != kMiss);
+    const int ncand = __builtin_popcountll(cands);
+    if (ncand == 0) {
       key.t = kInf, key.idx = kMiss, key.det = 0;
+    } else if (ncand <= 2) {
+      const int la = __builtin_ctzll(cands);
+      const int lb = ncand == 2 ? __builtin_ctzll(cands & (cands - 1)) : la;
+      const double ta = readLane(bestT, la), tb = readLane(bestT, lb);
+      const uint32_t ia = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bestIdx), la));
+      const uint32_t ib = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bestIdx), lb));
+      // strictly nearer wins; an exact tie goes to the lower combined index (Scene.cpp:31,95,118)
+      const bool pickB = uniformBool(tb < ta || (tb == ta && ib < ia));
+      const int lw = pickB ? lb : la;
+      key.t = pickB ? tb : ta;
+      key.idx = pickB ? ib : ia;
+      key.det = readLane(bestDet, lw);
     } else {
+      unsigned tHi, tLo;
+      const double tmin = waveMinPositive(bestT, tHi, tLo);
       unsigned long long owner = __builtin_amdgcn_ballot_w64(
           static_cast<unsigned>(hi32(bestT)) == tHi && static_cast<unsigned>(lo32(bestT)) == tLo);
       uint32_t imin;
