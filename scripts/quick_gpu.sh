@@ -1,2 +1,5 @@
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
-timeout 600 python scripts/quick_bench.py suzanne,64,64,256,0 suzanne,64,64,512,0 ce,16,16,256,0 ce,16,16,1024,0 cornell,128,128,256,0 2>&1 | grep -v amdgpu.ids
+mkdir -p gpurun_out
+timeout 1500 python bench.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/bench_full_r01e.json
+timeout 900 python bench.py --scene suzanne --spp 512 --width 256 --height 256 --no-cpu-baseline 2>&1 | grep -v amdgpu.ids | tee gpurun_out/bench_suzanne_r01e.json
+timeout 900 python bench.py --scene ce --spp 1024 --width 64 --height 64 --no-cpu-baseline 2>&1 | grep -v amdgpu.ids | tee gpurun_out/bench_ce_r01e.json
+bash scripts/profile_gpu.sh r01e > gpurun_out/profile_r01e.log 2>&1
