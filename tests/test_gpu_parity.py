@@ -282,3 +282,60 @@ def test_kernel_variants_on_random_soups(pkg, ob, ntri, nsph, policy):
     rgb, cnt, words = gpu_render_with_words(pkg, scene, cam, params)
     assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words)
     assert rel_err(rgb, ref_rgb) < TOL
+
+
+# ---- edge cases -------------------------------------------------------------------------------
+@pytest.mark.parametrize("policy", [0, 1])
+def test_edge_cases(pkg, ob, policy):
+    # empty scene: every ray leaves to the environment (Scene.cpp:131-133), 8 words per sample
+    scene = pkg.Scene()
+    scene.set_environment_colour((0.25, 0.5, 0.75))
+    cam = pkg.set_focus(pkg.look_at((0, 0, 5), (0, 0, 0), (0, 1, 0), 7, 5, 40.0), (0, 0, 0), 0.05)
+    params = pkg.default_params(width=7, height=5, samples_per_pixel=3, seed=2, rng_policy=policy)
+    rgb, cnt, words = gpu_render_with_words(pkg, scene, cam, params)
+    assert np.all(words == 8) and np.all(cnt == 3)
+    assert np.array_equal(rgb, np.broadcast_to(np.array([0.25, 0.5, 0.75]) * 3, rgb.shape))
+    # 1 x 1 frame, one pass; and a tall 1-pixel-wide frame
+    for (w, h, spp) in ((1, 1, 1), (1, 9, 2), (13, 1, 2)):
+        scene = pkg.Scene()
+        cam = scene.build_named("cornell", w, h)
+        params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=11, rng_policy=policy)
+        ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(scene.view(), cam, params, threads=1)
+        rgb, cnt, words = gpu_render_with_words(pkg, scene, cam, params)
+        assert np.array_equal(words, ref_words) and np.array_equal(cnt, ref_cnt)
+        assert rel_err(rgb, ref_rgb) < TOL
+    # zero passes: nothing happens, buffers untouched
+    params = pkg.default_params(width=13, height=1, samples_per_pixel=0, seed=11, rng_policy=policy)
+    rgb0, cnt0 = pkg.render(scene, cam, params, rgb_sum=np.full((1, 13, 3), 2.5), counts=np.full((1, 13), 4, np.uint32))
+    assert np.all(rgb0 == 2.5) and np.all(cnt0 == 4)
+
+
+def test_many_passes_small_frame(pkg, ob):
+    """More passes than the chip has SIMDs (queued workgroups), accumulated in pass order."""
+    scene = pkg.Scene()
+    cam = scene.build_named("cornell", 4, 3)
+    params = pkg.default_params(width=4, height=3, samples_per_pixel=1500, seed=1)
+    rgb, cnt = pkg.render(scene, cam, params)
+    ref_rgb, ref_cnt, _, _ = ob.oracle_render(scene.view(), cam, params, threads=8, want_words=False)
+    assert np.array_equal(cnt, ref_cnt) and rel_err(rgb, ref_rgb) < TOL
+
+
+def test_argument_errors(pkg):
+    scene = pkg.Scene()
+    cam = scene.build_named("single-sphere", 4, 4)
+    for over, status in ((dict(max_depth=65), 8), (dict(samples_per_pixel=-1), 1),
+                         (dict(rng_policy=7), 1), (dict(row_begin=3, row_end=2), 1), (dict(device=99), 2)):
+        kw = dict(width=4, height=4, samples_per_pixel=1, seed=1)
+        kw.update(over)
+        with pytest.raises(pkg.PtwError) as e:
+            pkg.render(scene, cam, pkg.default_params(**kw),
+                       rgb_sum=np.zeros((4, 4, 3)), counts=np.zeros((4, 4), np.uint32))
+        assert e.value.status == status, (over, e.value)
+    bad = pkg.default_params(width=0, height=4, samples_per_pixel=1, seed=1)
+    view = scene.view()
+    buf = np.zeros(64)
+    assert pkg.lib.ptw_render(C.byref(view), C.byref(cam), C.byref(bad), buf.ctypes.data, buf.ctypes.data,
+                              None, None) == 1
+    ctx = pkg.Context(0)
+    with pytest.raises(pkg.PtwError):  # render before set_scene
+        ctx.render(cam, pkg.default_params(width=4, height=4, samples_per_pixel=1, seed=1), 1, 1)
