@@ -240,6 +240,14 @@ __device__ __forceinline__ void waveSync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS traffic, not
+// for its outstanding global stores (which __syncthreads() would also drain).
+__device__ __forceinline__ void ldsBarrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <int Ctrl, int RowMask>
 __device__ __forceinline__ double dppMove(double x) {
   // lanes the DPP pattern does not feed keep their own value (old = x, bound_ctrl = 0)

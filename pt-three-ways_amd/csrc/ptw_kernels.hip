@@ -477,38 +477,9 @@ struct SeqCtx {
     }
   }
 
-  // This wave's part of Scene::intersect (Scene.cpp:115-122): its lanes' resident primitives
-  // against the ray, then the wave-level nearest hit with the reference's tie-break.
-  __device__ __forceinline__ HitKey localNearest(d3 o, d3 d) {
-    PTW_T(tA);
-    double bestT = kInf, bestDet = 0;
-    uint32_t bestIdx = kMiss;
-    const uint32_t nsph = p->nsph;
-    // spheres first (lower combined index)
-    if (hasSphere) testSphere(o, d, mk(scx, scy, scz), sr2, static_cast<uint32_t>(tid), bestT, bestIdx);
-    if (nsph > static_cast<uint32_t>(kThreads)) // rare: more spheres than lanes
-      for (uint32_t i = tid + kThreads; i < nsph; i += kThreads) {
-        const SphereRec &r = spheresGlobal[i];
-        testSphere(o, d, ld3(r.centre), r.radiusSquared, i, bestT, bestIdx);
-      }
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s)
-      testTriangle(o, d, mk(v0x[s], v0y[s], v0z[s]), mk(e1x[s], e1y[s], e1z[s]),
-                   mk(e2x[s], e2y[s], e2z[s]), nsph + static_cast<uint32_t>(tid) * SLOTS + s,
-                   bestT, bestIdx, bestDet);
-    // rare: more triangles than resident slots -> stream the remainder from memory
-    if (p->ntri > static_cast<uint32_t>(kThreads) * SLOTS)
-      for (uint32_t k = static_cast<uint32_t>(kThreads) * SLOTS + tid; k < p->ntri; k += kThreads) {
-        const double *g = triGeom + 9 * static_cast<size_t>(k);
-        testTriangle(o, d, ld3(g), ld3(g + 3), ld3(g + 6), nsph + k, bestT, bestIdx, bestDet);
-      }
-
-    // wave reduction: lexicographic min of (t, idx)
-#if PTW_PROFILE_PHASES
-    asm volatile("" : "+v"(bestT));
-#endif
-    PTW_T(tB);
-    PTW_ACC(0, tA, tB);
+  // The nearest of the lanes' candidates (t, combined index, determinant) with the reference's
+  // tie-break, as a wave-uniform result.
+  __device__ __forceinline__ static HitKey pickNearest(double bestT, uint32_t bestIdx, double bestDet) {
     HitKey key;
     // Most rays leave at most two lanes with a candidate (the line through a closed scene crosses
     // few primitives on its positive side): pick the nearer of them with scalar code instead of
@@ -546,6 +517,42 @@ struct SeqCtx {
       key.idx = imin;
       key.det = readLane(bestDet, __builtin_ctzll(owner));
     }
+    return key;
+  }
+
+  // This wave's part of Scene::intersect (Scene.cpp:115-122): its lanes' resident primitives
+  // against the ray, then the wave-level nearest hit with the reference's tie-break.
+  __device__ __forceinline__ HitKey localNearest(d3 o, d3 d) {
+    PTW_T(tA);
+    double bestT = kInf, bestDet = 0;
+    uint32_t bestIdx = kMiss;
+    const uint32_t nsph = p->nsph;
+    // spheres first (lower combined index)
+    if (hasSphere) testSphere(o, d, mk(scx, scy, scz), sr2, static_cast<uint32_t>(tid), bestT, bestIdx);
+    if (nsph > static_cast<uint32_t>(kThreads)) // rare: more spheres than lanes
+      for (uint32_t i = tid + kThreads; i < nsph; i += kThreads) {
+        const SphereRec &r = spheresGlobal[i];
+        testSphere(o, d, ld3(r.centre), r.radiusSquared, i, bestT, bestIdx);
+      }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s)
+      testTriangle(o, d, mk(v0x[s], v0y[s], v0z[s]), mk(e1x[s], e1y[s], e1z[s]),
+                   mk(e2x[s], e2y[s], e2z[s]), nsph + static_cast<uint32_t>(tid) * SLOTS + s,
+                   bestT, bestIdx, bestDet);
+    // rare: more triangles than resident slots -> stream the remainder from memory
+    if (p->ntri > static_cast<uint32_t>(kThreads) * SLOTS)
+      for (uint32_t k = static_cast<uint32_t>(kThreads) * SLOTS + tid; k < p->ntri; k += kThreads) {
+        const double *g = triGeom + 9 * static_cast<size_t>(k);
+        testTriangle(o, d, ld3(g), ld3(g + 3), ld3(g + 6), nsph + k, bestT, bestIdx, bestDet);
+      }
+
+    // wave reduction: lexicographic min of (t, idx)
+#if PTW_PROFILE_PHASES
+    asm volatile("" : "+v"(bestT));
+#endif
+    PTW_T(tB);
+    PTW_ACC(0, tA, tB);
+    HitKey key = pickNearest(bestT, bestIdx, bestDet);
 #if PTW_PROFILE_PHASES
     asm volatile("" : "+v"(key.t));
 #endif
@@ -562,26 +569,24 @@ struct SeqCtx {
   __device__ __forceinline__ HitKey intersect(d3 o, d3 d) {
     rays++;
     if (WAVES == 1) return localNearest(o, d);
+    PTW_T(tM0);
     if (threadIdx.x == 0) {
       cmd->o[0] = o.x, cmd->o[1] = o.y, cmd->o[2] = o.z;
       cmd->d[0] = d.x, cmd->d[1] = d.y, cmd->d[2] = d.z;
       cmd->op = kCmdTrace;
     }
-    __syncthreads(); // B1: ray visible to the workers
-    __syncthreads(); // B2: partial results visible
-    HitKey best;
-    best.t = kInf, best.idx = kMiss, best.det = 0;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
-      const PartialHit ph = partials[w];
-      if (ph.t < best.t || (ph.t == best.t && ph.idx < best.idx)) {
-        best.t = ph.t, best.idx = ph.idx, best.det = ph.det;
-      }
+    ldsBarrier(); // B1: ray visible to the workers
+    ldsBarrier(); // B2: partial results visible
+    // lane w of the master takes worker w's result; the same pick as inside a wave finishes it
+    double ct = kInf, cdet = 0;
+    uint32_t cidx = kMiss;
+    if ((threadIdx.x & 63) < WAVES) {
+      const PartialHit ph = partials[threadIdx.x & 63];
+      ct = ph.t, cidx = ph.idx, cdet = ph.det;
     }
-    HitKey key;
-    key.t = readFirstLane(best.t);
-    key.det = readFirstLane(best.det);
-    key.idx = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(best.idx)));
+    const HitKey key = pickNearest(ct, cidx, cdet);
+    PTW_T(tM1);
+    PTW_ACC(5, tM0, tM1);
     return key;
   }
 
@@ -593,7 +598,7 @@ struct SeqCtx {
     const unsigned long long w0 = __builtin_amdgcn_s_memtime();
 #endif
     for (;;) {
-      __syncthreads(); // B1
+      ldsBarrier(); // B1
       if (cmd->op == kCmdExit) break;
       const d3 o = mk(cmd->o[0], cmd->o[1], cmd->o[2]);
       const d3 d = mk(cmd->d[0], cmd->d[1], cmd->d[2]);
@@ -603,7 +608,7 @@ struct SeqCtx {
         ph.t = mine.t, ph.det = mine.det, ph.idx = mine.idx, ph.pad = 0;
         partials[tid >> 6] = ph;
       }
-      __syncthreads(); // B2
+      ldsBarrier(); // B2
 #if PTW_PROFILE_PHASES
       nreq++;
 #endif
@@ -619,7 +624,7 @@ struct SeqCtx {
   __device__ __forceinline__ void stopWorkers() {
     if (WAVES == 1) return;
     if (threadIdx.x == 0) cmd->op = kCmdExit;
-    __syncthreads(); // pairs with the workers' B1
+    ldsBarrier(); // pairs with the workers' B1
   }
 
   __device__ __forceinline__ bool branch(bool b) const { return uniformBool(b); }
@@ -873,10 +878,11 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + 1)) void traceSeque
   if (pass == 0 && threadIdx.x == 0) {
     const unsigned long long tEnd = __builtin_amdgcn_s_memtime();
     const double r = static_cast<double>(ctx.rays);
-    printf("PHASES rays=%llu total/ray=%.0f tests=%.0f reduce=%.0f surface=%.0f (lds1=%.0f) scatter=%.0f other=%.0f\n",
+    printf("PHASES rays=%llu total/ray=%.0f tests=%.0f reduce=%.0f surface=%.0f (lds1=%.0f) scatter=%.0f "
+           "xwave=%.0f other=%.0f\n",
            ctx.rays, (tEnd - tStart) / r, ctx.prof[0] / r, ctx.prof[1] / r, ctx.prof[2] / r,
-           ctx.prof[4] / r, ctx.prof[3] / r,
-           ((tEnd - tStart) - ctx.prof[0] - ctx.prof[1] - ctx.prof[2] - ctx.prof[3]) / r);
+           ctx.prof[4] / r, ctx.prof[3] / r, ctx.prof[5] / r,
+           ((tEnd - tStart) - ctx.prof[0] - ctx.prof[1] - ctx.prof[2] - ctx.prof[3] - ctx.prof[5]) / r);
   }
 #endif
   ctx.stopWorkers();
