@@ -65,10 +65,10 @@ def parse_args():
     return ap.parse_args()
 
 
-def timed_render(ctx, cam, params, rgb, cnt, steps, world, reduce_to_root):
-    """Times `steps` full renders (+ the framebuffer reduce when world > 1)."""
+def timed_render(ctx, cam, params, rgb, cnt, steps, use_dist, reduce_to_root):
+    """Times `steps` full renders (+ the framebuffer reduce under torch.distributed)."""
     stream = torch.cuda.current_stream().cuda_stream
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -77,7 +77,7 @@ def timed_render(ctx, cam, params, rgb, cnt, steps, world, reduce_to_root):
         if reduce_to_root:
             SHARDING.reduce_framebuffer(rgb, cnt, dst=0)  # the one data-path collective (RCCL)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     return time.perf_counter() - t0
 
@@ -123,8 +123,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # launched by torch.distributed.run (even with one rank): one process per GPU over RCCL
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world:
         if rank == 0:
@@ -159,16 +163,16 @@ def main():
     ctx.render(cam, tiny, rgb.data_ptr(), cnt.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     if args.warmup > 0:
-        timed_render(ctx, cam, params, rgb, cnt, args.warmup, world, world > 1)
+        timed_render(ctx, cam, params, rgb, cnt, args.warmup, use_dist, use_dist)
     rgb.zero_()
     cnt.zero_()
 
     ctx.enable_stats(True)
     ctx.stats(reset=True)
-    elapsed = timed_render(ctx, cam, params, rgb, cnt, args.steps, world, world > 1)
+    elapsed = timed_render(ctx, cam, params, rgb, cnt, args.steps, use_dist, use_dist)
     stats = ctx.stats(reset=True)
     ctx.enable_stats(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -242,7 +246,7 @@ def main():
             cnt2 = torch.zeros_like(cnt)
             ctx.enable_stats(True)
             ctx.stats(reset=True)
-            dt2 = timed_render(ctx, cam, p2, rgb2, cnt2, 1, 1, False)
+            dt2 = timed_render(ctx, cam, p2, rgb2, cnt2, 1, False, False)
             s2 = ctx.stats(reset=True)
             ctx.enable_stats(False)
             fl = s2.rays * (ntri * FLOP_PER_TRI_TEST + nsph * FLOP_PER_SPHERE_TEST)
@@ -263,7 +267,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(pkg, args.scene, args.cpu_threads)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

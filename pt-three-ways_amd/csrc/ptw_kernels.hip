@@ -233,8 +233,10 @@ __device__ __forceinline__ d3 radianceChain(CTX &ctx, const TraceParams &p,
       // Last level: the child is radiance(depth + 1 >= maxDepth) = 0 (Scene.cpp:128), so this
       // level returns E + 0 or E + D * 0 = E whatever the lobe; the new direction is never
       // used.  Only the three draws it consumes matter to the stream.
+      const unsigned long long tE0 = ctx.now();
       ctx.skip3();
       L = ctx.emissionAt(k);
+      ctx.acc(8, tE0, L.x);
       break;
     }
     const Surface s = ctx.surfaceAt(k, o, d, false);
@@ -242,16 +244,18 @@ __device__ __forceinline__ d3 radianceChain(CTX &ctx, const TraceParams &p,
     const unsigned long long tS0 = ctx.now();
     d3 nd;
     const bool refl = ctx.scatterChain(s, d, nd);
-    ctx.addScatter(tS0, nd.x);
+    ctx.acc(3, tS0, nd.x);
     ctx.push(nlev++, s.emission, s.diffuse, refl, k.idx);
     o = s.pos;
     d = nd;
   }
   // fold: result = 0 + (E + T * child); result / 1 (both exact no-ops on the value)
+  const unsigned long long tF0 = ctx.now();
   for (int i = nlev - 1; i >= 0; --i) {
     const Level lv = ctx.top(i);
     L = ctx.branch(lv.reflective) ? lv.emission + L : lv.emission + lv.diffuse * L;
   }
+  ctx.acc(7, tF0, L.x);
   return L;
 }
 
@@ -269,6 +273,7 @@ __device__ __forceinline__ d3 radiance0(CTX &ctx, const TraceParams &p, const Tr
     for (int vS = 0; vS < p.fbV; ++vS) {
       // (double(uSample) + unit(rng)) / double(numUSamples): a power-of-two divisor is an exact
       // scaling, so multiply by its reciprocal; otherwise divide.
+      const unsigned long long tB0 = ctx.now();
       double xu, xv, pd;
       ctx.draw3(xu, xv, pd);
       const double ur = static_cast<double>(uS) + xu;
@@ -277,6 +282,7 @@ __device__ __forceinline__ d3 radiance0(CTX &ctx, const TraceParams &p, const Tr
       const double v = p.vPow2 ? vr * p.invV : vr / static_cast<double>(p.fbV);
       d3 nd;
       const bool refl = scatter(ctx, s, d, u, v, pd, nd);
+      ctx.acc(6, tB0, nd.x);
       const d3 child = radianceChain(ctx, p, triShade, spheres, s.pos, nd);
       result = result + (refl ? s.emission + child : s.emission + s.diffuse * child);
     }
@@ -398,7 +404,7 @@ struct SeqCtx {
   unsigned long long rays;
   unsigned parity;
 #if PTW_PROFILE_PHASES
-  unsigned long long prof[8];
+  unsigned long long prof[12];
 #endif
 
   __device__ __forceinline__ void loadPrimitives() {
@@ -425,7 +431,15 @@ struct SeqCtx {
   }
 
   // Only the master wave draws random numbers, so it regenerates on its own.
-  __device__ __forceinline__ void regenerate() { mtRegenerateWave(sh, threadIdx.x & 63); }
+  __device__ __forceinline__ void regenerate() {
+#if PTW_PROFILE_PHASES
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+    mtRegenerateWave(sh, threadIdx.x & 63);
+#if PTW_PROFILE_PHASES
+    prof[9] += __builtin_amdgcn_s_memtime() - t0;
+#endif
+  }
 
   // Rebuild canon[] from the current raw state without twisting (state resumed mid-block).
   __device__ __forceinline__ void rebuildCanon() {
@@ -593,7 +607,7 @@ struct SeqCtx {
   // Worker waves (WAVES > 1, wave != 0): serve nearest-hit requests until told to stop.
   __device__ __forceinline__ void workerLoop() {
 #if PTW_PROFILE_PHASES
-    for (int i = 0; i < 8; ++i) prof[i] = 0;
+    for (int i = 0; i < 12; ++i) prof[i] = 0;
     unsigned long long nreq = 0;
     const unsigned long long w0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -687,13 +701,13 @@ struct SeqCtx {
   }
 #if PTW_PROFILE_PHASES
   __device__ __forceinline__ unsigned long long now() const { return __builtin_amdgcn_s_memtime(); }
-  __device__ __forceinline__ void addScatter(unsigned long long t0, double &keep) {
+  __device__ __forceinline__ void acc(int slot, unsigned long long t0, double &keep) {
     asm volatile("" : "+v"(keep));
-    prof[3] += __builtin_amdgcn_s_memtime() - t0;
+    prof[slot] += __builtin_amdgcn_s_memtime() - t0;
   }
 #else
   __device__ __forceinline__ unsigned long long now() const { return 0; }
-  __device__ __forceinline__ void addScatter(unsigned long long, double &) {}
+  __device__ __forceinline__ void acc(int, unsigned long long, double &) {}
 #endif
   __device__ __forceinline__ void push(int level, d3 e, d3 dif, bool refl, uint32_t) {
     // One lane stores (64 lanes writing one address would serialise in the LDS); every lane
@@ -848,7 +862,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + 1)) void traceSeque
   const bool lens = p.cam.aperture_radius != 0;
   double *myStage = stage + static_cast<size_t>(pass) * p.pixCount * 3;
 #if PTW_PROFILE_PHASES
-  for (int i = 0; i < 8; ++i) ctx.prof[i] = 0;
+  for (int i = 0; i < 12; ++i) ctx.prof[i] = 0;
   const unsigned long long tStart = __builtin_amdgcn_s_memtime();
 #endif
   for (uint32_t i = 0; i < p.pixCount; ++i) {
@@ -856,6 +870,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + 1)) void traceSeque
     const int px = static_cast<int>(pix % static_cast<uint32_t>(w));
     const int py = static_cast<int>(pix / static_cast<uint32_t>(w));
     ctx.words = 0;
+    const unsigned long long tC0 = ctx.now();
     double r0, r1, r2 = 0, r3 = 0;
     if (lens) {
       ctx.draw4(r0, r1, r2, r3);
@@ -865,6 +880,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + 1)) void traceSeque
     }
     d3 o, d;
     cameraRay(p.cam, px, py, r0, r1, r2, r3, o, d);
+    ctx.acc(10, tC0, d.x);
     const d3 L = radiance0(ctx, p, triShade, spheres, o, d);
     if (threadIdx.x == 0) {
       myStage[i * 3 + 0] = L.x;
@@ -879,10 +895,12 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + 1)) void traceSeque
     const unsigned long long tEnd = __builtin_amdgcn_s_memtime();
     const double r = static_cast<double>(ctx.rays);
     printf("PHASES rays=%llu total/ray=%.0f tests=%.0f reduce=%.0f surface=%.0f (lds1=%.0f) scatter=%.0f "
-           "xwave=%.0f other=%.0f\n",
+           "xwave=%.0f first=%.0f fold=%.0f lastE=%.0f regen=%.0f camera=%.0f other=%.0f\n",
            ctx.rays, (tEnd - tStart) / r, ctx.prof[0] / r, ctx.prof[1] / r, ctx.prof[2] / r,
-           ctx.prof[4] / r, ctx.prof[3] / r, ctx.prof[5] / r,
-           ((tEnd - tStart) - ctx.prof[0] - ctx.prof[1] - ctx.prof[2] - ctx.prof[3] - ctx.prof[5]) / r);
+           ctx.prof[4] / r, ctx.prof[3] / r, ctx.prof[5] / r, ctx.prof[6] / r, ctx.prof[7] / r,
+           ctx.prof[8] / r, ctx.prof[9] / r, ctx.prof[10] / r,
+           ((tEnd - tStart) - ctx.prof[0] - ctx.prof[1] - ctx.prof[2] - ctx.prof[3] - ctx.prof[5] -
+            ctx.prof[6] - ctx.prof[7] - ctx.prof[8] - ctx.prof[10]) / r);
   }
 #endif
   ctx.stopWorkers();
@@ -944,7 +962,7 @@ struct PixCtx {
     return scatter(*this, s, dirIn, u, v, pd, dirOut);
   }
   __device__ __forceinline__ unsigned long long now() const { return 0; }
-  __device__ __forceinline__ void addScatter(unsigned long long, double &) {}
+  __device__ __forceinline__ void acc(int, unsigned long long, double &) {}
   __device__ __forceinline__ void draw3(double &a, double &b, double &c) {
     a = draw();
     b = draw();

@@ -43,7 +43,7 @@ def row_shard(rank: int, world: int, height: int) -> tuple[int, int]:
 
 def reduce_framebuffer(rgb_sum: torch.Tensor, counts: torch.Tensor, dst: int = 0) -> None:
     """output += pass for whole framebuffers: sums every rank's buffers into rank `dst`."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return
     dist.reduce(rgb_sum, dst=dst, op=dist.ReduceOp.SUM)
     dist.reduce(counts, dst=dst, op=dist.ReduceOp.SUM)
