@@ -251,10 +251,7 @@ __device__ __forceinline__ d3 radianceChain(CTX &ctx, const TraceParams &p,
   }
   // fold: result = 0 + (E + T * child); result / 1 (both exact no-ops on the value)
   const unsigned long long tF0 = ctx.now();
-  for (int i = nlev - 1; i >= 0; --i) {
-    const Level lv = ctx.top(i);
-    L = ctx.branch(lv.reflective) ? lv.emission + L : lv.emission + lv.diffuse * L;
-  }
+  for (int i = nlev - 1; i >= 0; --i) L = ctx.fold(i, L);
   ctx.acc(7, tF0, L.x);
   return L;
 }
@@ -375,8 +372,23 @@ struct SeqTables {
   const SphereRec *sph;  // [nsph]                        (LDS or global)
 };
 
-template <int SLOTS, int WAVES, bool LDS_TABLES>
+// Layout of the per-lane shading record of the REG path (doubles).
+constexpr int kRecNormal = 0, kRecBasisX = 3, kRecBasisY = 6, kRecEmission = 9, kRecDiffuse = 12,
+              kRecIor = 15, kRecInvIor = 16, kRecReflectivity = 17, kRecCone = 18, kRecDoubles = 19;
+
+template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false>
 struct SeqCtx {
+  // REG (single wave, one triangle per lane, at most 127 primitives, maxDepth <= 9): every lane
+  // also keeps the SHADING record of its triangle in registers and the (E, T) stack is one byte
+  // per level in a scalar register pair.  A hit then fetches the winner's record with
+  // v_readlane instead of two dependent LDS round trips, and pushing / folding a level touches no
+  // memory at all: with one wave per SIMD nothing hides an LDS wait, while a readlane costs one
+  // issue slot.
+  static_assert(!REG || (SLOTS == 1 && WAVES == 1), "REG needs one wave and one triangle per lane");
+  double rec[REG ? kRecDoubles : 1];
+  unsigned long long stackBits; // REG: level i in bits [8i, 8i+8): combined index | lobe << 7
+  unsigned long long emissiveMask; // REG: lanes whose triangle has a non-zero emission
+
   // WAVES == 1: one wave does everything.  WAVES > 1: WAVES worker waves hold the primitives
   // and one extra master wave (wave 0, no resident primitives) runs the path logic.
   static constexpr int kThreads = 64 * WAVES;                        // lanes that hold primitives
@@ -393,6 +405,8 @@ struct SeqCtx {
   const TraceParams *p;
   const double *triGeom;
   const SphereRec *spheresGlobal;
+  const double *triCompactGlobal; // REG: source of the per-lane shading records
+  const double *matTableGlobal;
   SeqTables tab;
   SeqShared *sh;
   Level *stack;          // this wave's private radiance stack in LDS
@@ -420,6 +434,27 @@ struct SeqCtx {
       v0x[s] = valid ? g[0] : 0.0, v0y[s] = valid ? g[1] : 0.0, v0z[s] = valid ? g[2] : 0.0;
       e1x[s] = valid ? g[3] : 0.0, e1y[s] = valid ? g[4] : 0.0, e1z[s] = valid ? g[5] : 0.0;
       e2x[s] = valid ? g[6] : 0.0, e2y[s] = valid ? g[7] : 0.0, e2z[s] = valid ? g[8] : 0.0;
+    }
+    if (REG) {
+      // lanes without a triangle never win a hit, their record is never read
+#pragma unroll
+      for (int i = 0; i < kRecDoubles; ++i) rec[i] = 0.0;
+      if (static_cast<uint32_t>(tid) < ntri) {
+        const double *r = triCompactGlobal + static_cast<size_t>(tid) * kTriCompactDoubles;
+        const double *m = matTableGlobal + static_cast<size_t>(static_cast<uint32_t>(r[9])) * kMatDoubles;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) rec[i] = r[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) rec[kRecEmission + i] = m[i];
+        rec[kRecIor] = m[6];
+        rec[kRecInvIor] = m[7];
+        rec[kRecReflectivity] = m[8];
+        rec[kRecCone] = m[9];
+      }
+      const bool emissive = rec[kRecEmission] != 0.0 || rec[kRecEmission + 1] != 0.0 ||
+                            rec[kRecEmission + 2] != 0.0;
+      emissiveMask = __builtin_amdgcn_ballot_w64(emissive);
+      stackBits = 0;
     }
     hasSphere = static_cast<uint32_t>(tid) < p->nsph;
     if (hasSphere) {
@@ -643,7 +678,15 @@ struct SeqCtx {
 
   __device__ __forceinline__ bool branch(bool b) const { return uniformBool(b); }
 
+  __device__ __forceinline__ d3 recD3(int at, int lane) const {
+    return mk(readLane(rec[at], lane), readLane(rec[at + 1], lane), readLane(rec[at + 2], lane));
+  }
   __device__ __forceinline__ d3 emissionAt(const HitKey &k) const {
+    if (REG && k.idx >= p->nsph) {
+      const int lane = static_cast<int>(k.idx - p->nsph);
+      if (!((emissiveMask >> lane) & 1ull)) return mk(0, 0, 0);
+      return recD3(kRecEmission, lane);
+    }
     if (k.idx >= p->nsph) {
       const double *r = tab.tri + static_cast<size_t>(k.idx - p->nsph) * kTriCompactDoubles;
       return ld3(tab.mat + static_cast<size_t>(static_cast<uint32_t>(r[9])) * kMatDoubles);
@@ -709,7 +752,15 @@ struct SeqCtx {
   __device__ __forceinline__ unsigned long long now() const { return 0; }
   __device__ __forceinline__ void acc(int, unsigned long long, double &) {}
 #endif
-  __device__ __forceinline__ void push(int level, d3 e, d3 dif, bool refl, uint32_t) {
+  __device__ __forceinline__ void push(int level, d3 e, d3 dif, bool refl, uint32_t idx) {
+    if (REG) {
+      const unsigned sh8 = static_cast<unsigned>(level) * 8u;
+      const unsigned long long w =
+          static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<int>(idx)) & 0x7f) |
+          (refl ? 0x80ull : 0ull);
+      stackBits = (stackBits & ~(0xffull << sh8)) | (w << sh8);
+      return;
+    }
     // One lane stores (64 lanes writing one address would serialise in the LDS); every lane
     // reads it back later.  The address is the same for the store and the loads, so the
     // compiler keeps them ordered.
@@ -721,7 +772,44 @@ struct SeqCtx {
       stack[level] = lv;
     }
   }
-  __device__ __forceinline__ Level top(int level) const { return stack[level]; }
+  __device__ __forceinline__ Level top(int level) const {
+    if (REG) {
+      const unsigned w = static_cast<unsigned>(stackBits >> (static_cast<unsigned>(level) * 8u)) & 0xffu;
+      const uint32_t idx = w & 0x7fu;
+      Level lv;
+      lv.reflective = (w >> 7) != 0;
+      if (idx >= p->nsph) {
+        const int lane = static_cast<int>(idx - p->nsph);
+        lv.emission = recD3(kRecEmission, lane);
+        lv.diffuse = recD3(kRecDiffuse, lane);
+      } else {
+        lv.emission = ld3(tab.sph[idx].emission);
+        lv.diffuse = ld3(tab.sph[idx].diffuse);
+      }
+      return lv;
+    }
+    return stack[level];
+  }
+
+  // One step of the innermost-first fold: L_level = E + T * L_child (Scene.cpp:163-175).
+  __device__ __forceinline__ d3 fold(int level, d3 L) const {
+    if (REG) {
+      const unsigned w = static_cast<unsigned>(stackBits >> (static_cast<unsigned>(level) * 8u)) & 0xffu;
+      const uint32_t idx = w & 0x7fu;
+      const bool refl = (w >> 7) != 0;
+      if (idx >= p->nsph) {
+        const int lane = static_cast<int>(idx - p->nsph);
+        if (!((emissiveMask >> lane) & 1ull)) {
+          // E == +0 and the child radiance is never negative: E + x == x exactly
+          return refl ? L : recD3(kRecDiffuse, lane) * L;
+        }
+        const d3 e = recD3(kRecEmission, lane);
+        return refl ? e + L : e + recD3(kRecDiffuse, lane) * L;
+      }
+    }
+    const Level lv = top(level);
+    return uniformBool(lv.reflective) ? lv.emission + L : lv.emission + lv.diffuse * L;
+  }
 
   // Surface at a hit from the shading tables (same values as makeSurface()).
   __device__ __forceinline__ Surface surfaceAt(const HitKey &k, d3 o, d3 d, bool eager = true) {
@@ -793,7 +881,7 @@ __host__ __device__ inline size_t seqLdsBytes(int waves, int maxDepth, bool ldsT
   return n;
 }
 
-template <int SLOTS, int WAVES, bool LDS_TABLES>
+template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false>
 __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + 1)) void traceSequential(
     const TraceParams p, const double *__restrict__ triGeom,
     const TriShade *__restrict__ triShade, const SphereRec *__restrict__ spheres,
@@ -811,12 +899,14 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + 1)) void traceSeque
   off = (off + 63) & ~static_cast<size_t>(63);
 
   const int pass = blockIdx.x;
-  SeqCtx<SLOTS, WAVES, LDS_TABLES> ctx;
+  SeqCtx<SLOTS, WAVES, LDS_TABLES, REG> ctx;
+  ctx.triCompactGlobal = triCompact;
+  ctx.matTableGlobal = matTable;
   ctx.p = &p;
   ctx.triGeom = triGeom;
   ctx.spheresGlobal = spheres;
   ctx.sh = &sh;
-  constexpr int kBlock = SeqCtx<SLOTS, WAVES, LDS_TABLES>::kBlock;
+  constexpr int kBlock = SeqCtx<SLOTS, WAVES, LDS_TABLES, REG>::kBlock;
   const bool isWorker = WAVES > 1 && threadIdx.x >= 64;
   ctx.tid = WAVES == 1 ? threadIdx.x : (isWorker ? threadIdx.x - 64 : threadIdx.x);
   ctx.stack = stacks; // only the master wave uses the radiance stack
@@ -987,6 +1077,11 @@ struct PixCtx {
       lv.diffuse = ld3(spheres[idx].diffuse);
     }
     return lv;
+  }
+  // one step of the innermost-first fold: L_level = E + T * L_child (Scene.cpp:163-175)
+  __device__ __forceinline__ d3 fold(int level, d3 L) const {
+    const Level lv = top(level);
+    return lv.reflective ? lv.emission + L : lv.emission + lv.diffuse * L;
   }
 
   __device__ __forceinline__ HitKey intersect(d3 o, d3 d) {
@@ -1459,9 +1554,9 @@ __global__ __launch_bounds__(64) void rngKatKernel(int rngPolicy,
 
 constexpr size_t kLdsTableBudget = 96 * 1024; // bytes of LDS we are willing to spend on tables
 
-template <int SLOTS, int WAVES, bool LDS_TABLES>
+template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false>
 hipError_t launchSeq(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
-  auto kernel = traceSequential<SLOTS, WAVES, LDS_TABLES>;
+  auto kernel = traceSequential<SLOTS, WAVES, LDS_TABLES, REG>;
   const size_t lds = seqLdsBytes(WAVES, p.maxDepth, LDS_TABLES, p.ntri, p.nmat, p.nsph);
   static size_t configured = 0; // per instantiation
   if (lds > 48 * 1024 && lds > configured) {
@@ -1492,7 +1587,15 @@ hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hi
   // Smallest configuration that keeps every triangle resident in VGPRs.  Up to 128 triangles
   // one wave does everything.  Beyond that 7 worker waves + 1 master wave = 8 waves = 2 per SIMD
   // of one CU (256 registers per lane each): SLOTS triangles per worker lane.
-  if (n <= 64) return launchSeqAuto<1, 1>(p, b, stream);
+  if (n <= 64) {
+    // register-resident shading records + scalar (E, T) stack when the byte-per-level encoding
+    // fits (PTW_SEQ_REG=0 forces the LDS-table variant for A/B runs)
+    static const char *regEnv = std::getenv("PTW_SEQ_REG");
+    const bool reg = !(regEnv && regEnv[0] == '0') && p.nsph + n <= 127 && p.maxDepth <= 9 &&
+                     seqLdsBytes(1, p.maxDepth, true, p.ntri, p.nmat, p.nsph) <= kLdsTableBudget;
+    if (reg) return launchSeq<1, 1, true, true>(p, b, stream);
+    return launchSeqAuto<1, 1>(p, b, stream);
+  }
   if (n <= 128) return launchSeqAuto<2, 1>(p, b, stream);
   if (n <= 448) return launchSeqAuto<1, 7>(p, b, stream);
   if (n <= 896) return launchSeqAuto<2, 7>(p, b, stream);

@@ -3,7 +3,8 @@ cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=/tmp/pmcq; rm -rf $OUT; mkdir -p $OUT
 ARGS=${1:-cornell,128,128,256,0}
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA -d $OUT -o q -- python $REPO/scripts/quick_bench.py $ARGS > $OUT/log 2>&1
+COUNTERS=${PMC:-SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA}
+rocprofv3 --pmc $COUNTERS -d $OUT -o q -- python $REPO/scripts/quick_bench.py $ARGS > $OUT/log 2>&1
 grep Msamples $OUT/log || tail -20 $OUT/log; find $OUT -name "*.db" | head
 python3 - <<'PY'
 import sqlite3, glob
