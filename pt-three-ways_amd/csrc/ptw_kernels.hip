@@ -373,17 +373,18 @@ struct SeqTables {
 };
 
 // Layout of the per-lane shading record of the REG path (doubles).
-constexpr int kRecNormal = 0, kRecBasisX = 3, kRecBasisY = 6, kRecEmission = 9, kRecDiffuse = 12,
-              kRecIor = 15, kRecInvIor = 16, kRecReflectivity = 17, kRecCone = 18, kRecDoubles = 19;
+constexpr int kRecEmission = 0, kRecDiffuse = 3, kRecDoubles = 6;
 
 template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false>
 struct SeqCtx {
   // REG (single wave, one triangle per lane, at most 127 primitives, maxDepth <= 9): every lane
-  // also keeps the SHADING record of its triangle in registers and the (E, T) stack is one byte
-  // per level in a scalar register pair.  A hit then fetches the winner's record with
-  // v_readlane instead of two dependent LDS round trips, and pushing / folding a level touches no
-  // memory at all: with one wave per SIMD nothing hides an LDS wait, while a readlane costs one
-  // issue slot.
+  // also keeps the emission and diffuse colour of its triangle in registers, and the (E, T)
+  // stack is one byte per level (combined primitive index + lobe flag) in a scalar register
+  // pair.  Pushing a level is three scalar instructions; folding one fetches the colours from
+  // the owner lane with v_readlane (only the diffuse colour when the emission is zero): no LDS
+  // traffic, and with one wave per SIMD nothing would hide an LDS wait.  (Fetching the whole
+  // surface record that way was measured and is slower: one ds_read_b128 moves what four
+  // v_readlane do.)
   static_assert(!REG || (SLOTS == 1 && WAVES == 1), "REG needs one wave and one triangle per lane");
   double rec[REG ? kRecDoubles : 1];
   unsigned long long stackBits; // REG: level i in bits [8i, 8i+8): combined index | lobe << 7
@@ -443,13 +444,7 @@ struct SeqCtx {
         const double *r = triCompactGlobal + static_cast<size_t>(tid) * kTriCompactDoubles;
         const double *m = matTableGlobal + static_cast<size_t>(static_cast<uint32_t>(r[9])) * kMatDoubles;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) rec[i] = r[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) rec[kRecEmission + i] = m[i];
-        rec[kRecIor] = m[6];
-        rec[kRecInvIor] = m[7];
-        rec[kRecReflectivity] = m[8];
-        rec[kRecCone] = m[9];
+        for (int i = 0; i < 6; ++i) rec[i] = m[i]; // emission, diffuse
       }
       const bool emissive = rec[kRecEmission] != 0.0 || rec[kRecEmission + 1] != 0.0 ||
                             rec[kRecEmission + 2] != 0.0;
