@@ -280,7 +280,7 @@ __device__ __forceinline__ d3 radiance0(CTX &ctx, const TraceParams &p, const Tr
       d3 nd;
       const bool refl = scatter(ctx, s, d, u, v, pd, nd);
       ctx.acc(6, tB0, nd.x);
-      const d3 child = radianceChain(ctx, p, triShade, spheres, s.pos, nd);
+      const d3 child = ctx.runChain(p, triShade, spheres, s.pos, nd);
       result = result + (refl ? s.emission + child : s.emission + s.diffuse * child);
     }
   }
@@ -442,7 +442,7 @@ struct SeqCtx {
       for (int i = 0; i < kRecDoubles; ++i) rec[i] = 0.0;
       if (static_cast<uint32_t>(tid) < ntri) {
         const double *r = triCompactGlobal + static_cast<size_t>(tid) * kTriCompactDoubles;
-        const double *m = matTableGlobal + static_cast<size_t>(static_cast<uint32_t>(r[9])) * kMatDoubles;
+        const double *m = matTableGlobal + static_cast<size_t>(static_cast<uint32_t>(r[kTriMaterialIndex])) * kMatDoubles;
 #pragma unroll
         for (int i = 0; i < 6; ++i) rec[i] = m[i]; // emission, diffuse
       }
@@ -573,7 +573,7 @@ struct SeqCtx {
     const uint32_t nsph = p->nsph;
     // spheres first (lower combined index)
     if (hasSphere) testSphere(o, d, mk(scx, scy, scz), sr2, static_cast<uint32_t>(tid), bestT, bestIdx);
-    if (nsph > static_cast<uint32_t>(kThreads)) // rare: more spheres than lanes
+    if (!REG && nsph > static_cast<uint32_t>(kThreads)) // rare: more spheres than lanes
       for (uint32_t i = tid + kThreads; i < nsph; i += kThreads) {
         const SphereRec &r = spheresGlobal[i];
         testSphere(o, d, ld3(r.centre), r.radiusSquared, i, bestT, bestIdx);
@@ -584,7 +584,7 @@ struct SeqCtx {
                    mk(e2x[s], e2y[s], e2z[s]), nsph + static_cast<uint32_t>(tid) * SLOTS + s,
                    bestT, bestIdx, bestDet);
     // rare: more triangles than resident slots -> stream the remainder from memory
-    if (p->ntri > static_cast<uint32_t>(kThreads) * SLOTS)
+    if (!REG && p->ntri > static_cast<uint32_t>(kThreads) * SLOTS)
       for (uint32_t k = static_cast<uint32_t>(kThreads) * SLOTS + tid; k < p->ntri; k += kThreads) {
         const double *g = triGeom + 9 * static_cast<size_t>(k);
         testTriangle(o, d, ld3(g), ld3(g + 3), ld3(g + 6), nsph + k, bestT, bestIdx, bestDet);
@@ -684,7 +684,7 @@ struct SeqCtx {
     }
     if (k.idx >= p->nsph) {
       const double *r = tab.tri + static_cast<size_t>(k.idx - p->nsph) * kTriCompactDoubles;
-      return ld3(tab.mat + static_cast<size_t>(static_cast<uint32_t>(r[9])) * kMatDoubles);
+      return ld3(tab.mat + static_cast<size_t>(static_cast<uint32_t>(r[kTriMaterialIndex])) * kMatDoubles);
     }
     return ld3(tab.sph[k.idx].emission);
   }
@@ -786,6 +786,78 @@ struct SeqCtx {
     return stack[level];
   }
 
+  __device__ __forceinline__ d3 runChain(const TraceParams &tp, const TriShade *ts, const SphereRec *sp,
+                                         d3 o, d3 d) {
+    if (REG) return chainHot(tp, o, d);
+    return radianceChain(*this, tp, ts, sp, o, d);
+  }
+
+  // radianceChain() for the REG variant, arranged around what a single wave per SIMD pays for:
+  // every instruction is one issue slot, and a branch - even an untaken one - costs five to ten
+  // of them (scripts/microbench/issue_costs.hip).  The common case, a chain level that hits a
+  // triangle and takes the diffuse lobe with its three draws inside the current generator block,
+  // is decided by TWO branches: one on scalar facts about the hit, one on the lobe predicate
+  // (evaluated as lane-mask logic from the per-triangle lobe threshold, see ptw_layout.h).  All
+  // its LDS operands (triangle record, draws, draw-derived local direction) are requested
+  // together and waited for once.  Everything else - miss, last level, sphere, reflective lobe,
+  // Fresnel evaluation, draws straddling a regeneration - takes the general code below, which
+  // is the same sequence radianceChain() runs.
+  //   backfacing hits: surfaceAt() negates the normal and basis.x; negation commutes exactly
+  //   with the products of transform(), so the signs go onto the local direction instead.
+  __device__ __forceinline__ d3 chainHot(const TraceParams &tp, d3 o, d3 d) {
+    int nlev = 0;
+    d3 L;
+    const int maxDepth = tp.maxDepth;
+    const uint32_t nsph = tp.nsph;
+    if (maxDepth <= 1) return mk(0, 0, 0); // Scene.cpp:128 at depth 1
+    for (int depth = 1;; ++depth) {
+      const HitKey k = intersect(o, d);
+      const bool hot = (k.idx != kMiss) & (k.idx >= nsph) & (depth + 1 < maxDepth) &
+                       (pos + 3 <= kMtDoubles);
+      if (hot) {
+        const double *r = tab.tri + static_cast<size_t>(k.idx - nsph) * kTriCompactDoubles;
+        const int q = pos;
+        const d3 n = ld3(r), bx = ld3(r + 3), by = ld3(r + 6);
+        const double thr = r[kTriLobeThreshold];
+        const double pd = sh->canon[q + 2];
+        const d3 local = mk(sh->hemi[q][0], sh->hemi[q][1], sh->hemi[q][2]);
+        const bool backfacing = k.det < kEpsilon; // Scene.cpp:107
+        const double ndotd = dot(n, d);
+        const double cosThetaI = backfacing ? ndotd : -ndotd; // -dot(+-n, d)
+        const bool sure = !(pd < thr) & ((thr >= 0.0) | ((cosThetaI >= 1e-3) & (pd > 0.0)));
+        if (uniformBool(sure)) {
+          pos += 3;
+          words += 6;
+          Basis b;
+          b.x = bx, b.y = by, b.z = n;
+          const double sgn = backfacing ? -1.0 : 1.0;
+          const d3 nd = normalisedNearUnit(transform(b, mk(local.x * sgn, local.y, local.z * sgn)));
+          o = o + d * k.t;
+          d = nd;
+          push(nlev++, mk(0, 0, 0), mk(0, 0, 0), false, k.idx);
+          continue;
+        }
+      }
+      if (uniformBool(k.idx == kMiss)) { // Scene.cpp:131-133
+        L = ld3(tp.env);
+        break;
+      }
+      if (depth + 1 >= maxDepth) { // last level: see radianceChain()
+        skip3();
+        L = emissionAt(k);
+        break;
+      }
+      const Surface s = surfaceAt(k, o, d, false);
+      d3 nd;
+      const bool refl = scatterChain(s, d, nd);
+      push(nlev++, s.emission, s.diffuse, refl, k.idx);
+      o = s.pos;
+      d = nd;
+    }
+    for (int i = nlev - 1; i >= 0; --i) L = fold(i, L);
+    return L;
+  }
+
   // One step of the innermost-first fold: L_level = E + T * L_child (Scene.cpp:163-175).
   __device__ __forceinline__ d3 fold(int level, d3 L) const {
     if (REG) {
@@ -829,7 +901,7 @@ struct SeqCtx {
       s.basis.x = backfacing ? -bx : bx;
       s.basis.y = ld3(r + 6);
       s.basis.z = s.normal;
-      const double *m = tab.mat + static_cast<size_t>(static_cast<uint32_t>(r[9])) * kMatDoubles;
+      const double *m = tab.mat + static_cast<size_t>(static_cast<uint32_t>(r[kTriMaterialIndex])) * kMatDoubles;
       s.emission = ld3(m);
       s.diffuse = ld3(m + 3);
       ior = m[6], invIor = m[7], reflectivity = m[8];
@@ -1078,6 +1150,10 @@ struct PixCtx {
     const Level lv = top(level);
     return lv.reflective ? lv.emission + L : lv.emission + lv.diffuse * L;
   }
+  __device__ __forceinline__ d3 runChain(const TraceParams &tp, const TriShade *ts, const SphereRec *sp,
+                                         d3 o, d3 d) {
+    return radianceChain(*this, tp, ts, sp, o, d);
+  }
 
   __device__ __forceinline__ HitKey intersect(d3 o, d3 d) {
     rays++;
@@ -1325,7 +1401,7 @@ __global__ __launch_bounds__(kPix2Block) __attribute__((amdgpu_waves_per_eu(4, 4
               s.basis.x = backfacing ? -bx : bx;
               s.basis.y = ld3(r + 6);
               s.basis.z = s.normal;
-              const double *m = matTable + static_cast<size_t>(static_cast<uint32_t>(r[9])) * kMatDoubles;
+              const double *m = matTable + static_cast<size_t>(static_cast<uint32_t>(r[kTriMaterialIndex])) * kMatDoubles;
               s.emission = ld3(m);
               s.diffuse = ld3(m + 3);
               ior = m[6], invIor = m[7], reflectivity = m[8];
@@ -1402,7 +1478,7 @@ __global__ __launch_bounds__(kPix2Block) __attribute__((amdgpu_waves_per_eu(4, 4
             const double *m =
                 idx >= nsph
                     ? matTable + static_cast<size_t>(static_cast<uint32_t>(
-                                     triCompact[static_cast<size_t>(idx - nsph) * kTriCompactDoubles + 9])) *
+                                     triCompact[static_cast<size_t>(idx - nsph) * kTriCompactDoubles + kTriMaterialIndex])) *
                                      kMatDoubles
                     : spheres[idx].emission; // SphereRec: emission[3] then diffuse[3]
             const d3 e = ld3(m), df = ld3(m + 3);
@@ -1586,7 +1662,8 @@ hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hi
     // register-resident shading records + scalar (E, T) stack when the byte-per-level encoding
     // fits (PTW_SEQ_REG=0 forces the LDS-table variant for A/B runs)
     static const char *regEnv = std::getenv("PTW_SEQ_REG");
-    const bool reg = !(regEnv && regEnv[0] == '0') && p.nsph + n <= 127 && p.maxDepth <= 9 &&
+    const bool reg = !(regEnv && regEnv[0] == '0') && p.nsph <= 64 && p.nsph + n <= 127 &&
+                     p.maxDepth <= 9 &&
                      seqLdsBytes(1, p.maxDepth, true, p.ntri, p.nmat, p.nsph) <= kLdsTableBudget;
     if (reg) return launchSeq<1, 1, true, true>(p, b, stream);
     return launchSeqAuto<1, 1>(p, b, stream);

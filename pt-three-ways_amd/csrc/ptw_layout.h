@@ -39,10 +39,19 @@ struct alignas(64) SphereRec {
 }; // 16 doubles = 128 B
 
 // Compact per-triangle record for the LDS-resident shading table of the SEQUENTIAL kernel:
-// normal, basisX, basisY (as in TriShade) + the material index as a double.  Materials sit in
-// their own table of kMatDoubles doubles each: emission, diffuse, ior, 1/ior, reflectivity,
-// cone angle.
-constexpr int kTriCompactDoubles = 10;
+// normal, basisX, basisY (as in TriShade), the material index as a double, and the material's
+// "lobe threshold" (kTriLobeThreshold) so the common diffuse bounce needs no second, dependent
+// fetch of the material:
+//   reflectivity >= 0            -> the reflectivity itself: diffuse lobe iff !(p < threshold)
+//   reflectivity < 0, ior == 1   -> -1: Norm3::reflectance is below the spacing of the draws
+//                                   unless the ray grazes (see lobeIsReflective), so the lobe is
+//                                   diffuse iff cos(theta_i) >= 1e-3 and p > 0 - else evaluate
+//   reflectivity < 0, ior != 1   -> 2: always evaluate Norm3::reflectance
+// One pad double keeps records 16-byte aligned (96 B) for ds_read_b128.  Materials sit in their
+// own table of kMatDoubles doubles each: emission, diffuse, ior, 1/ior, reflectivity, cone angle.
+constexpr int kTriCompactDoubles = 12;
+constexpr int kTriMaterialIndex = 9;
+constexpr int kTriLobeThreshold = 10;
 constexpr int kMatDoubles = 10;
 
 constexpr int kMtWords = 624;

@@ -70,7 +70,9 @@ DeviceSceneData precomputeScene(const ptw_scene_view &scene) {
                  r.reflectivity, r.coneAngle);
     double *c = &out.triCompact[static_cast<size_t>(i) * kTriCompactDoubles];
     normal.store(c), bx.store(c + 3), by.store(c + 6);
-    c[9] = static_cast<double>(scene.tri_material[i]);
+    c[kTriMaterialIndex] = static_cast<double>(scene.tri_material[i]);
+    c[kTriLobeThreshold] = r.reflectivity >= 0 ? r.reflectivity : (r.ior == 1.0 ? -1.0 : 2.0);
+    c[11] = 0.0;
   }
 
   for (uint32_t i = 0; i < scene.num_spheres; ++i) {
