@@ -808,36 +808,50 @@ struct SeqCtx {
     int nlev = 0;
     d3 L;
     const int maxDepth = tp.maxDepth;
-    const uint32_t nsph = tp.nsph;
+    const uint32_t nsph = tp.nsph, ntri = tp.ntri;
     if (maxDepth <= 1) return mk(0, 0, 0); // Scene.cpp:128 at depth 1
-    for (int depth = 1;; ++depth) {
-      const HitKey k = intersect(o, d);
-      const bool hot = (k.idx != kMiss) & (k.idx >= nsph) & (depth + 1 < maxDepth) &
-                       (pos + 3 <= kMtDoubles);
-      if (hot) {
+    int depth = 1;
+    for (;;) {
+      HitKey k;
+      // ---- hot loop: stays inside while every level is a diffuse triangle bounce ----
+      for (;;) {
+        k = intersect(o, d);
+        // hit a triangle (not a miss, not a sphere), not the last level, draws inside the block:
+        // three differences that are all negative exactly then
+        const int notLast = depth + 1 - maxDepth;       // < 0
+        const int inBlock = pos + 2 - kMtDoubles;       // < 0  <=>  pos + 3 <= kMtDoubles
+        const bool isTri = (k.idx - nsph) < ntri;       // unsigned: kMiss and spheres fail
+        if (!(isTri & ((notLast & inBlock) < 0))) break;
         const double *r = tab.tri + static_cast<size_t>(k.idx - nsph) * kTriCompactDoubles;
         const int q = pos;
-        const d3 n = ld3(r), bx = ld3(r + 3), by = ld3(r + 6);
-        const double thr = r[kTriLobeThreshold];
-        const double pd = sh->canon[q + 2];
-        const d3 local = mk(sh->hemi[q][0], sh->hemi[q][1], sh->hemi[q][2]);
+        d3 n = ld3(r), bx = ld3(r + 3), by = ld3(r + 6);
+        double thr = r[kTriLobeThreshold];
+        double pd = sh->canon[q + 2];
+        d3 local = mk(sh->hemi[q][0], sh->hemi[q][1], sh->hemi[q][2]);
+        // one wait for everything: without this the loads the lobe test does not need sink below
+        // its branch and are waited for a second time
+        asm volatile("" : "+v"(n.x), "+v"(bx.x), "+v"(by.x), "+v"(thr), "+v"(pd), "+v"(local.x));
         const bool backfacing = k.det < kEpsilon; // Scene.cpp:107
         const double ndotd = dot(n, d);
         const double cosThetaI = backfacing ? ndotd : -ndotd; // -dot(+-n, d)
-        const bool sure = !(pd < thr) & ((thr >= 0.0) | ((cosThetaI >= 1e-3) & (pd > 0.0)));
-        if (uniformBool(sure)) {
-          pos += 3;
-          words += 6;
-          Basis b;
-          b.x = bx, b.y = by, b.z = n;
-          const double sgn = backfacing ? -1.0 : 1.0;
-          const d3 nd = normalisedNearUnit(transform(b, mk(local.x * sgn, local.y, local.z * sgn)));
-          o = o + d * k.t;
-          d = nd;
-          push(nlev++, mk(0, 0, 0), mk(0, 0, 0), false, k.idx);
-          continue;
-        }
+        // lobe predicate as lane-mask logic (all lanes agree)
+        const unsigned long long mNotRefl = __builtin_amdgcn_ballot_w64(!(pd < thr));
+        const unsigned long long mPlain = __builtin_amdgcn_ballot_w64(thr >= 0.0);
+        const unsigned long long mCos = __builtin_amdgcn_ballot_w64(cosThetaI >= 1e-3);
+        const unsigned long long mPos = __builtin_amdgcn_ballot_w64(pd > 0.0);
+        if ((mNotRefl & (mPlain | (mCos & mPos))) == 0) break;
+        pos += 3;
+        words += 6;
+        Basis b;
+        b.x = bx, b.y = by, b.z = n;
+        const double sgn = backfacing ? -1.0 : 1.0;
+        const d3 nd = normalisedNearUnit(transform(b, mk(local.x * sgn, local.y, local.z * sgn)));
+        o = o + d * k.t;
+        d = nd;
+        push(nlev++, mk(0, 0, 0), mk(0, 0, 0), false, k.idx);
+        ++depth;
       }
+      // ---- general path: miss, last level, sphere, reflective lobe, straddling draws ----
       if (uniformBool(k.idx == kMiss)) { // Scene.cpp:131-133
         L = ld3(tp.env);
         break;
@@ -853,6 +867,7 @@ struct SeqCtx {
       push(nlev++, s.emission, s.diffuse, refl, k.idx);
       o = s.pos;
       d = nd;
+      ++depth;
     }
     for (int i = nlev - 1; i >= 0; --i) L = fold(i, L);
     return L;
