@@ -135,8 +135,9 @@ __device__ __forceinline__ double reflectance(d3 n, d3 incoming, double iorFrom,
 // error < 1 ulp).  Arguments outside [0, 6.5] take ocml's sincos (out of line).
 __device__ __noinline__ void sincosGeneral(double x, double *s, double *c) { sincos(x, s, c); }
 
+template <bool IN_RANGE = false> // IN_RANGE: the caller guarantees 0 <= x <= 6.5
 __device__ __forceinline__ void sinCos(double x, double &sn, double &cs) {
-  if (!(x >= 0.0 && x <= 6.5)) {
+  if (!IN_RANGE && !(x >= 0.0 && x <= 6.5)) {
     sincosGeneral(x, &sn, &cs);
     return;
   }
@@ -193,7 +194,7 @@ __device__ __forceinline__ d3 hemisphereSample(const Basis &basis, double u, dou
 #if PTW_ABLATE == 1
   s = theta * 0.1; c = 1.0 - s;
 #else
-  sinCos(theta, s, c);
+  sinCos<true>(theta, s, c); // u is a (stratified) canonical draw: theta in [0, 2 pi)
 #endif
   // (c r, s r, sqrt(1 - v)) has squared length v + (1 - v) and the basis is orthonormal, so the
   // transformed vector is unit length up to a few ulp
@@ -208,7 +209,7 @@ __device__ __noinline__ d3 coneSample(d3 direction, double coneTheta, double u, 
   sinCos(coneTheta, radius, zScale);
   const double randomTheta = v * 2 * kPi;
   double s, c;
-  sinCos(randomTheta, s, c);
+  sinCos<true>(randomTheta, s, c); // v is a (stratified) canonical draw
   const Basis basis = basisFromZ(direction);
   return normalised(transform(basis, mk(c * radius, s * radius, zScale)));
 }

@@ -179,7 +179,7 @@ __device__ __forceinline__ void cameraRay(const ptw_camera &c, int px, int py, d
   const double angle = r2 * (2 * kPi - 0) + 0;      // uniform_real_distribution(0, 2*pi)
   const double radius = r3 * (c.aperture_radius - 0) + 0;
   double sn, cs;
-  sinCos(angle, sn, cs);
+  sinCos<true>(angle, sn, cs); // r2 in [0, 1)
   const d3 origin = (centre + (ax * cs) * radius) + (ay * sn) * radius;
   o = origin;
   d = normalised(focalPoint - origin); // Ray::fromTwoPoints, Ray.h:12-15
@@ -274,9 +274,15 @@ __device__ __forceinline__ d3 radiance0(CTX &ctx, const TraceParams &p, const Tr
       double xu, xv, pd;
       ctx.draw3(xu, xv, pd);
       const double ur = static_cast<double>(uS) + xu;
-      const double u = p.uPow2 ? ur * p.invU : ur / static_cast<double>(p.fbU);
       const double vr = static_cast<double>(vS) + xv;
-      const double v = p.vPow2 ? vr * p.invV : vr / static_cast<double>(p.fbV);
+      double u, v;
+      if ((p.uPow2 & p.vPow2) != 0) { // one decision for the usual 4x4 / 2x2 / 1x1 fan-outs
+        u = ur * p.invU;
+        v = vr * p.invV;
+      } else {
+        u = p.uPow2 ? ur * p.invU : ur / static_cast<double>(p.fbU);
+        v = p.vPow2 ? vr * p.invV : vr / static_cast<double>(p.fbV);
+      }
       d3 nd;
       const bool refl = scatter(ctx, s, d, u, v, pd, nd);
       ctx.acc(6, tB0, nd.x);
@@ -328,7 +334,7 @@ __device__ __forceinline__ void fillHemiTable(SeqShared *sh, int lane) {
     const double theta = (2 * kPi) * u;
     const double radius = sqrtPos(v);
     double sn, cs;
-    sinCos(theta, sn, cs);
+    sinCos<true>(theta, sn, cs);
     sh->hemi[q][0] = cs * radius;
     sh->hemi[q][1] = sn * radius;
     sh->hemi[q][2] = sqrtPos(1 - v);
