@@ -536,37 +536,42 @@ struct SeqCtx {
     // a 64-lane reduction.
     const unsigned long long cands = __builtin_amdgcn_ballot_w64(bestIdx != kMiss);
     const int ncand = __builtin_popcountll(cands);
+    // Only the sign test `det < epsilon` of the winner's determinant is ever used: it travels as
+    // bit 31 of the index word, which saves the two cross-lane reads of the determinant (a
+    // v_readlane with a computed lane costs a lone wave four issue slots).
+    const uint32_t packed = bestIdx | (bestDet < kEpsilon ? 0x80000000u : 0u);
+    uint32_t pw;
     if (ncand == 0) {
       key.t = kInf, key.idx = kMiss, key.det = 0;
-    } else if (ncand <= 2) {
+      return key;
+    } else if (ncand == 1) {
       const int la = __builtin_ctzll(cands);
-      const int lb = ncand == 2 ? __builtin_ctzll(cands & (cands - 1)) : la;
+      key.t = readLane(bestT, la);
+      pw = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(packed), la));
+    } else if (ncand == 2) {
+      const int la = __builtin_ctzll(cands);
+      const int lb = __builtin_ctzll(cands & (cands - 1));
       const double ta = readLane(bestT, la), tb = readLane(bestT, lb);
-      const uint32_t ia = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bestIdx), la));
-      const uint32_t ib = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bestIdx), lb));
+      const uint32_t pa = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(packed), la));
+      const uint32_t pb = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(packed), lb));
       // strictly nearer wins; an exact tie goes to the lower combined index (Scene.cpp:31,95,118)
-      const bool pickB = uniformBool(tb < ta || (tb == ta && ib < ia));
-      const int lw = pickB ? lb : la;
+      const bool pickB = uniformBool((tb < ta) | ((tb == ta) & ((pb & 0x7fffffffu) < (pa & 0x7fffffffu))));
       key.t = pickB ? tb : ta;
-      key.idx = pickB ? ib : ia;
-      key.det = readLane(bestDet, lw);
+      pw = pickB ? pb : pa;
     } else {
       unsigned tHi, tLo;
       const double tmin = waveMinPositive(bestT, tHi, tLo);
       unsigned long long owner = __builtin_amdgcn_ballot_w64(
           static_cast<unsigned>(hi32(bestT)) == tHi && static_cast<unsigned>(lo32(bestT)) == tLo);
-      uint32_t imin;
-      if (__builtin_popcountll(owner) == 1) { // the usual case: a unique nearest lane
-        imin = static_cast<uint32_t>(
-            __builtin_amdgcn_readlane(static_cast<int>(bestIdx), __builtin_ctzll(owner)));
-      } else { // exact tie between lanes: lowest combined index wins
-        imin = waveMinUFused(bestT == tmin ? bestIdx : kMiss);
+      if (__builtin_popcountll(owner) != 1) { // exact tie between lanes: lowest combined index wins
+        const uint32_t imin = waveMinUFused(bestT == tmin ? bestIdx : kMiss);
         owner = __builtin_amdgcn_ballot_w64(bestIdx == imin);
       }
       key.t = tmin;
-      key.idx = imin;
-      key.det = readLane(bestDet, __builtin_ctzll(owner));
+      pw = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(packed), __builtin_ctzll(owner)));
     }
+    key.idx = pw & 0x7fffffffu;
+    key.det = (pw >> 31) ? -1.0 : 1.0;
     return key;
   }
 
