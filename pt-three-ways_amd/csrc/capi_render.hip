@@ -67,6 +67,7 @@ struct ptw_context {
   DeviceArray<TriShade> triShade;
   DeviceArray<SphereRec> spheres;
   DeviceArray<double> triCompact, matTable;
+  DeviceArray<double> specState; // parked stream rings of traceSequentialSpec
   uint32_t nmat = 0;
   DeviceArray<uint32_t> mtState, mtPos;
   DeviceArray<double> stage;
@@ -205,6 +206,7 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
                          hipMemcpyHostToDevice, stream),
           "H2D mtPos");
     check(hipStreamSynchronize(stream), "sync after seeding"); // `pos` is a local
+    ctx.specState.reserve(static_cast<size_t>(npass) * kSpecStateDoubles);
   }
 
   TraceBuffers b;
@@ -221,6 +223,7 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   b.rays = ctx.rays.ptr;
   ctx.sampleQueue.reserve(1);
   b.sampleQueue = ctx.sampleQueue.ptr;
+  b.specState = sequential ? ctx.specState.ptr : nullptr;
 
   auto timedLaunch = [&](bool trace, auto &&launch) {
     if (!ctx.statsEnabled) {
@@ -241,6 +244,7 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   for (uint32_t begin = pixFirst; begin < pixLast; begin += static_cast<uint32_t>(bandPix)) {
     t.pixBegin = begin;
     t.pixCount = static_cast<uint32_t>(std::min<uint64_t>(bandPix, pixLast - begin));
+    t.firstBand = begin == pixFirst;
     if (sequential)
       timedLaunch(true, [&] { return launchTraceSequential(t, b, stream); });
     else

@@ -25,6 +25,8 @@ struct TraceParams {
   uint32_t pixCount;     // pixels in the band
   uint32_t npix;         // width * height
   uint32_t npass;
+  int32_t firstBand;     // this launch starts the passes' streams (first band of a render)
+  int32_t padB;
 };
 
 struct TraceBuffers {
@@ -39,6 +41,7 @@ struct TraceBuffers {
   uint32_t *words;           // optional [npass][npix]
   unsigned long long *rays;  // optional [npass] intersect() call counters
   unsigned long long *sampleQueue; // one word: next sample index (tracePerPixelPersistent)
+  double *specState;         // [npass][kSpecStateDoubles] parked stream ring (traceSequentialSpec)
 };
 
 // SEQUENTIAL policy: one workgroup per pass walks the band's pixels in row-major order.

@@ -341,8 +341,15 @@ __device__ __forceinline__ void fillHemiTable(SeqShared *sh, int lane) {
   }
 }
 
-__device__ __noinline__ void mtRegenerateWave(SeqShared *sh, int lane) {
-  uint32_t *x = sh->mt;
+// SPEC (traceSequentialSpec): the generator output lives in a two-block ring in LDS, each block
+// with a few entries of overlap copied from its successor, so a group of consecutive draws never
+// straddles a regeneration and this context never regenerates: it only reads at (ringOff, pos).
+constexpr unsigned kRingStride = 16384;     // bytes between the two ring slots (XOR toggles)
+constexpr unsigned kRingHemiOff = 2560;     // hemi table inside a slot, after 316 canon doubles
+constexpr int kRingCanonDoubles = 316;      // 312 + 4 entries of the next block
+
+// The twist of all 624 state words by one wave (see the comment above).
+__device__ __forceinline__ void mtTwistWave(uint32_t *x, int lane) {
   waveSync();
   for (int base = 0; base < 227; base += 64) { // k in [0, 227): far = old x[k + 397]
     const int k = base + lane;
@@ -362,10 +369,46 @@ __device__ __noinline__ void mtRegenerateWave(SeqShared *sh, int lane) {
   }
   if (lane == 0) x[623] = mtTwist(x[623], x[0], x[396]);
   waveSync();
+}
+
+__device__ __noinline__ void mtRegenerateWave(SeqShared *sh, int lane) {
+  uint32_t *x = sh->mt;
+  mtTwistWave(x, lane);
   for (int i = lane; i < kMtDoubles; i += 64)
     sh->canon[i] = canonicalFromWords(mtTemper(x[2 * i]), mtTemper(x[2 * i + 1]));
   waveSync();
   fillHemiTable(sh, lane);
+  waveSync();
+}
+
+// One entry of the draw-derived hemisphere table (see SeqShared::hemi).
+__device__ __forceinline__ void hemiEntry(double u, double v, double *out) {
+  const double theta = (2 * kPi) * u;
+  const double radius = sqrtPos(v);
+  double sn, cs;
+  sinCos<true>(theta, sn, cs);
+  out[0] = cs * radius;
+  out[1] = sn * radius;
+  out[2] = sqrtPos(1 - v);
+}
+
+// SPEC ring: generates the next block of the stream into the slot at `slotOff` (one wave).  The
+// first entries of the new block are also the overlap of the block in the other slot, whose last
+// hemi entry becomes computable with them.
+__device__ __noinline__ void specGenerateBlock(uint32_t *x, char *ring, unsigned slotOff, int lane) {
+  mtTwistWave(x, lane);
+  double *canon = reinterpret_cast<double *>(ring + slotOff);
+  double *hemi = reinterpret_cast<double *>(ring + slotOff + kRingHemiOff);
+  double *otherCanon = reinterpret_cast<double *>(ring + (slotOff ^ kRingStride));
+  double *otherHemi = reinterpret_cast<double *>(ring + (slotOff ^ kRingStride) + kRingHemiOff);
+  for (int i = lane; i < kMtDoubles; i += 64)
+    canon[i] = canonicalFromWords(mtTemper(x[2 * i]), mtTemper(x[2 * i + 1]));
+  waveSync();
+  if (lane < kRingCanonDoubles - kMtDoubles) otherCanon[kMtDoubles + lane] = canon[lane];
+  waveSync();
+  for (int q = lane; q + 1 < kMtDoubles; q += 64) hemiEntry(canon[q], canon[q + 1], hemi + 3 * q);
+  if (lane == 0)
+    hemiEntry(otherCanon[kMtDoubles - 1], otherCanon[kMtDoubles], otherHemi + 3 * (kMtDoubles - 1));
   waveSync();
 }
 
@@ -381,7 +424,7 @@ struct SeqTables {
 // Layout of the per-lane shading record of the REG path (doubles).
 constexpr int kRecEmission = 0, kRecDiffuse = 3, kRecDoubles = 6;
 
-template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false>
+template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false, bool SPEC = false>
 struct SeqCtx {
   // REG (single wave, one triangle per lane, at most 127 primitives, maxDepth <= 9): every lane
   // also keeps the emission and diffuse colour of its triangle in registers, and the (E, T)
@@ -421,6 +464,8 @@ struct SeqCtx {
   SeqCommand *cmd;       // master -> workers (WAVES > 1)
   int tid;               // index among the primitive-holding lanes (workers); master: lane id
   int pos;               // next canonical double in sh->canon (wave-uniform)
+  char *ringBase;        // SPEC: LDS address of ring slot 0
+  unsigned ringOff;      // SPEC: 0 or kRingStride - the slot `pos` indexes
   unsigned words;        // RNG words consumed by the current sample
   unsigned long long rays;
   unsigned parity;
@@ -489,7 +534,32 @@ struct SeqCtx {
     __syncthreads();
   }
 
+  // SPEC accessors: canon / hemi of the slot `pos` indexes
+  __device__ __forceinline__ const double *ringCanon() const {
+    return reinterpret_cast<const double *>(ringBase + ringOff);
+  }
+  __device__ __forceinline__ const double *ringHemi(int q) const {
+    return reinterpret_cast<const double *>(ringBase + ringOff + kRingHemiOff) + 3 * q;
+  }
+  // SPEC: consume n draws (branch-free wrap into the other slot)
+  __device__ __forceinline__ void advance(int n) {
+    const int np = pos + n;
+    const bool wrap = np >= kMtDoubles;
+    pos = wrap ? np - kMtDoubles : np;
+    ringOff = wrap ? ringOff ^ kRingStride : ringOff;
+    words += 2 * n;
+  }
+  __device__ __forceinline__ void setStream(unsigned off, int q) {
+    ringOff = off;
+    pos = q;
+  }
+
   __device__ __forceinline__ double draw() {
+    if (SPEC) {
+      const double v = ringCanon()[pos];
+      advance(1);
+      return v;
+    }
     if (pos == kMtDoubles) {
       regenerate();
       pos = 0;
@@ -499,6 +569,12 @@ struct SeqCtx {
   }
   // consecutive draws with one LDS round trip when they do not straddle a regeneration
   __device__ __forceinline__ void draw3(double &a, double &b, double &c) {
+    if (SPEC) {
+      const double *cn = ringCanon() + pos;
+      a = cn[0], b = cn[1], c = cn[2];
+      advance(3);
+      return;
+    }
     if (pos + 3 <= kMtDoubles) {
       a = sh->canon[pos];
       b = sh->canon[pos + 1];
@@ -512,6 +588,12 @@ struct SeqCtx {
     }
   }
   __device__ __forceinline__ void draw4(double &a, double &b, double &c, double &d) {
+    if (SPEC) {
+      const double *cn = ringCanon() + pos;
+      a = cn[0], b = cn[1], c = cn[2], d = cn[3];
+      advance(4);
+      return;
+    }
     if (pos + 4 <= kMtDoubles) {
       a = sh->canon[pos];
       b = sh->canon[pos + 1];
@@ -701,6 +783,10 @@ struct SeqCtx {
   }
   // consume three draws without looking at them
   __device__ __forceinline__ void skip3() {
+    if (SPEC) {
+      advance(3);
+      return;
+    }
     if (pos + 3 <= kMtDoubles) {
       pos += 3;
       words += 6;
@@ -715,6 +801,19 @@ struct SeqCtx {
   // order (Scene.cpp:157-161).  When the three draws sit inside the current block, the diffuse
   // lobe takes its local direction from the precomputed table.
   __device__ __forceinline__ bool scatterChain(const Surface &s, d3 dirIn, d3 &dirOut) {
+    if (SPEC) {
+      const double *cn = ringCanon() + pos;
+      const double *hm = ringHemi(pos);
+      const double u = cn[0], v = cn[1], pd = cn[2];
+      const d3 local = mk(hm[0], hm[1], hm[2]);
+      advance(3);
+      if (uniformBool(lobeIsReflective(s, dirIn, pd))) { // Scene.cpp:163-168
+        dirOut = coneSample(reflect(s.normal, dirIn), s.coneAngle, u, v);
+        return true;
+      }
+      dirOut = normalisedNearUnit(transform(s.basis, local)); // Scene.cpp:169-175
+      return false;
+    }
     if (pos + 3 <= kMtDoubles) {
       const int q = pos;
       const double pd = sh->canon[q + 2];
@@ -830,15 +929,16 @@ struct SeqCtx {
         // hit a triangle (not a miss, not a sphere), not the last level, draws inside the block:
         // three differences that are all negative exactly then
         const int notLast = depth + 1 - maxDepth;       // < 0
-        const int inBlock = pos + 2 - kMtDoubles;       // < 0  <=>  pos + 3 <= kMtDoubles
+        const int inBlock = SPEC ? -1 : pos + 2 - kMtDoubles; // < 0  <=>  pos + 3 <= kMtDoubles
         const bool isTri = (k.idx - nsph) < ntri;       // unsigned: kMiss and spheres fail
         if (!(isTri & ((notLast & inBlock) < 0))) break;
         const double *r = tab.tri + static_cast<size_t>(k.idx - nsph) * kTriCompactDoubles;
         const int q = pos;
         d3 n = ld3(r), bx = ld3(r + 3), by = ld3(r + 6);
         double thr = r[kTriLobeThreshold];
-        double pd = sh->canon[q + 2];
-        d3 local = mk(sh->hemi[q][0], sh->hemi[q][1], sh->hemi[q][2]);
+        double pd = SPEC ? ringCanon()[q + 2] : sh->canon[q + 2];
+        const double *hm = SPEC ? ringHemi(q) : sh->hemi[q];
+        d3 local = mk(hm[0], hm[1], hm[2]);
         // one wait for everything: without this the loads the lobe test does not need sink below
         // its branch and are waited for a second time
         asm volatile("" : "+v"(n.x), "+v"(bx.x), "+v"(by.x), "+v"(thr), "+v"(pd), "+v"(local.x));
@@ -851,8 +951,12 @@ struct SeqCtx {
         const unsigned long long mCos = __builtin_amdgcn_ballot_w64(cosThetaI >= 1e-3);
         const unsigned long long mPos = __builtin_amdgcn_ballot_w64(pd > 0.0);
         if ((mNotRefl & (mPlain | (mCos & mPos))) == 0) break;
-        pos += 3;
-        words += 6;
+        if (SPEC) {
+          advance(3);
+        } else {
+          pos += 3;
+          words += 6;
+        }
         Basis b;
         b.x = bx, b.y = by, b.z = n;
         const double sgn = backfacing ? -1.0 : 1.0;
@@ -1094,6 +1198,295 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + 1)) void traceSeque
   if (threadIdx.x == 0) {
     mtPos[pass] = static_cast<uint32_t>(ctx.pos); // thread 0 belongs to the master wave
     if (rayCounters) rayCounters[pass] += ctx.rays;
+  }
+}
+
+// -----------------------------------------------------------------------------------------
+// traceSequentialSpec: SEQUENTIAL policy for scenes of at most 64 triangles, with the
+// sub-samples of the first-bounce fan-out traced SPECULATIVELY in parallel.
+//
+// The stream makes everything serial: sub-sample j+1 starts where sub-sample j stopped, and how
+// many draws j consumes (3 per level it reaches) is known only when it is done.  But that count
+// takes few values, and the values repeat (a closed scene mostly runs every path to the depth cap,
+// an open one mostly loses the first ray).  So a workgroup of kSpecWaves waves - one per SIMD of
+// a CU, each holding the whole scene in registers like the single-wave kernel - works per round
+// on:  wave 0: sub-sample j at the true stream position (the frontier);
+//      wave 1: sub-sample j+1, assuming j consumes m1 (the most recent count);
+//      wave 2: sub-sample j+1 assuming m2 (the most recent different count) - or, while no second
+//              value has been seen, sub-sample j+3 assuming m1 three times;
+//      wave 3: sub-sample j+2, assuming m1 twice.
+// After a barrier every wave reads all results and commits, in order, as many sub-samples as the
+// assumptions allow (always j; j+1 if a wave started where j really stopped; and so on).  Wrong
+// guesses cost nothing but the energy: the result is the one the serial order defines, bit for bit
+// - each wave accumulates the committed contributions itself, in sub-sample order.
+//
+// For that the stream must be readable ahead of the frontier: the generator output sits in a
+// ring of two blocks (SeqCtx SPEC mode); while the frontier is in one block the next one is
+// already there, and when the frontier crosses into it, wave 0 generates the block after it into
+// the slot that just became free.
+// -----------------------------------------------------------------------------------------
+constexpr int kSpecWaves = 4;
+
+struct SpecResult { // one per wave and round parity, in LDS
+  double L[3];      // radiance of the sub-path below the first-bounce surface
+  int consumed;     // canonical doubles the sub-sample consumed
+  int refl;         // lobe taken at the first-bounce surface
+  unsigned rays;    // intersect() calls
+  int pad;
+};
+
+__host__ __device__ inline size_t specLdsBytes(uint32_t ntri, uint32_t nmat, uint32_t nsph) {
+  size_t n = 2 * kRingStride;                          // the ring
+  n += kMtWords * sizeof(uint32_t);                    // raw generator state
+  n += 2 * kSpecWaves * sizeof(SpecResult);            // results, double-buffered
+  n = (n + 63) & ~static_cast<size_t>(63);
+  n += static_cast<size_t>(nsph) * sizeof(SphereRec);
+  n += static_cast<size_t>(ntri) * kTriCompactDoubles * sizeof(double);
+  n += static_cast<size_t>(nmat) * kMatDoubles * sizeof(double);
+  // more than half of a CU's 160 KB: one workgroup per CU, so its four waves get a SIMD each
+  const size_t floor = 84 * 1024;
+  return n < floor ? floor : n;
+}
+
+__global__ __launch_bounds__(64 * kSpecWaves) void traceSequentialSpec(
+    const TraceParams p, const double *__restrict__ triGeom, const SphereRec *__restrict__ spheres,
+    const double *__restrict__ triCompact, const double *__restrict__ matTable,
+    uint32_t *__restrict__ mtState, double *__restrict__ specState, double *__restrict__ stage,
+    uint32_t *__restrict__ words, unsigned long long *__restrict__ rayCounters) {
+  extern __shared__ __attribute__((aligned(64))) unsigned char ldsRaw[];
+  constexpr int kBlock = 64 * kSpecWaves;
+  char *ring = reinterpret_cast<char *>(ldsRaw);
+  uint32_t *mt = reinterpret_cast<uint32_t *>(ldsRaw + 2 * kRingStride);
+  SpecResult *results = reinterpret_cast<SpecResult *>(mt + kMtWords);
+  size_t off = 2 * kRingStride + kMtWords * sizeof(uint32_t) + 2 * kSpecWaves * sizeof(SpecResult);
+  off = (off + 63) & ~static_cast<size_t>(63);
+
+  const int pass = blockIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+
+  using Ctx = SeqCtx<1, 1, true, true, true>;
+  Ctx ctx;
+  ctx.triCompactGlobal = triCompact;
+  ctx.matTableGlobal = matTable;
+  ctx.p = &p;
+  ctx.triGeom = triGeom;
+  ctx.spheresGlobal = spheres;
+  ctx.sh = nullptr;
+  ctx.tid = lane; // every wave owns the whole scene: lane k holds triangle k
+  ctx.stack = nullptr;
+  ctx.partials = nullptr;
+  ctx.cmd = nullptr;
+  ctx.words = 0;
+  ctx.rays = 0;
+  ctx.parity = 0;
+  ctx.ringBase = ring;
+  {
+    SphereRec *ls = reinterpret_cast<SphereRec *>(ldsRaw + off);
+    double *lt = reinterpret_cast<double *>(ls + p.nsph);
+    double *lm = lt + static_cast<size_t>(p.ntri) * kTriCompactDoubles;
+    const double *gs = reinterpret_cast<const double *>(spheres);
+    double *lsd = reinterpret_cast<double *>(ls);
+    for (uint32_t i = threadIdx.x; i < p.nsph * (sizeof(SphereRec) / 8); i += kBlock) lsd[i] = gs[i];
+    for (uint32_t i = threadIdx.x; i < p.ntri * kTriCompactDoubles; i += kBlock) lt[i] = triCompact[i];
+    for (uint32_t i = threadIdx.x; i < p.nmat * kMatDoubles; i += kBlock) lm[i] = matTable[i];
+    ctx.tab.sph = ls;
+    ctx.tab.tri = lt;
+    ctx.tab.mat = lm;
+  }
+  ctx.loadPrimitives();
+
+  // ---- the stream: resume (or start) this pass's generator ring ----
+  uint32_t *myState = mtState + static_cast<size_t>(pass) * kMtWords;
+  double *myPark = specState + static_cast<size_t>(pass) * kSpecStateDoubles;
+  for (int i = threadIdx.x; i < kMtWords; i += kBlock) mt[i] = myState[i];
+  unsigned fOff = 0; // frontier: ring slot (0 or kRingStride) ...
+  int fQ = 0;        // ... and position in it
+  if (p.firstBand) {
+    __syncthreads();
+    if (wave == 0) {
+      specGenerateBlock(mt, ring, 0, lane);           // block 0
+      specGenerateBlock(mt, ring, kRingStride, lane); // block 1 (completes block 0's overlap)
+    }
+  } else {
+    for (int i = threadIdx.x; i < 2 * kRingCanonDoubles; i += kBlock) {
+      const int slot = i / kRingCanonDoubles, k = i - slot * kRingCanonDoubles;
+      reinterpret_cast<double *>(ring + slot * kRingStride)[k] = myPark[i];
+    }
+    fOff = __builtin_amdgcn_readfirstlane(static_cast<int>(myPark[2 * kRingCanonDoubles])) ? kRingStride : 0u;
+    fQ = __builtin_amdgcn_readfirstlane(static_cast<int>(myPark[2 * kRingCanonDoubles + 1]));
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * kMtDoubles; i += kBlock) {
+      const int slot = i / kMtDoubles, q = i - slot * kMtDoubles;
+      const double *cn = reinterpret_cast<const double *>(ring + slot * kRingStride);
+      hemiEntry(cn[q], cn[q + 1], reinterpret_cast<double *>(ring + slot * kRingStride + kRingHemiOff) + 3 * q);
+    }
+  }
+  __syncthreads();
+
+  // Moves the frontier by n draws; when it enters the other slot, wave 0 generates the block after
+  // it into the slot left behind.  Every wave calls this with the same n at the same point.
+  auto advanceFrontier = [&](int n) {
+    const int np = fQ + n;
+    if (np >= kMtDoubles) {
+      const unsigned oldOff = fOff;
+      fQ = np - kMtDoubles;
+      fOff ^= kRingStride;
+      ldsBarrier(); // nobody reads the old slot any more
+      if (wave == 0) specGenerateBlock(mt, ring, oldOff, lane);
+      ldsBarrier();
+    } else {
+      fQ = np;
+    }
+  };
+
+  const int w = p.width;
+  const bool lens = p.cam.aperture_radius != 0;
+  const int nSub = p.fbU * p.fbV;
+  double *myStage = stage + static_cast<size_t>(pass) * p.pixCount * 3;
+  unsigned long long raysTotal = 0;
+  int m1 = 3 * (p.maxDepth > 0 ? p.maxDepth : 1), m2 = m1; // recent consumption counts (draws)
+  int parity = 0;
+
+  for (uint32_t i = 0; i < p.pixCount; ++i) {
+    const uint32_t pix = p.pixBegin + i;
+    const int px = static_cast<int>(pix % static_cast<uint32_t>(w));
+    const int py = static_cast<int>(pix / static_cast<uint32_t>(w));
+    // ---- every wave: camera ray and first hit at the frontier (redundant, in parallel) ----
+    ctx.setStream(fOff, fQ);
+    double r0, r1, r2 = 0, r3 = 0;
+    if (lens) {
+      ctx.draw4(r0, r1, r2, r3);
+    } else {
+      r0 = ctx.draw();
+      r1 = ctx.draw();
+    }
+    const int camDraws = lens ? 4 : 2;
+    d3 o, d;
+    cameraRay(p.cam, px, py, r0, r1, r2, r3, o, d);
+    int sampleDraws = camDraws;
+    d3 L = mk(0, 0, 0);
+    bool traced = false;
+    HitKey k0;
+    k0.t = kInf, k0.idx = kMiss, k0.det = 0;
+    if (p.maxDepth > 0) {
+      k0 = ctx.intersect(o, d);
+      raysTotal++;
+      if (uniformBool(k0.idx == kMiss)) {
+        L = ld3(p.env);
+      } else {
+        traced = true;
+      }
+    }
+    advanceFrontier(camDraws);
+    if (traced) {
+      const Surface first = ctx.surfaceAt(k0, o, d);
+      if (p.preview) {
+        L = first.diffuse; // Scene.cpp:137-138
+      } else {
+        d3 result = mk(0, 0, 0);
+        int j = 0;
+        while (j < nSub) {
+          // ---- this wave's assignment: sub-sample j + ioff, stream position frontier + delta ----
+          const bool oneMode = m2 == m1;
+          int ioff = 0, delta = 0;
+          if (wave == 1) ioff = 1, delta = m1;
+          if (wave == 2) ioff = oneMode ? 3 : 1, delta = oneMode ? 3 * m1 : m2;
+          if (wave == 3) ioff = 2, delta = 2 * m1;
+          const int myIdx = j + ioff;
+          SpecResult mine;
+          mine.L[0] = mine.L[1] = mine.L[2] = 0;
+          mine.consumed = 0, mine.refl = 0, mine.rays = 0, mine.pad = 0;
+          if (myIdx < nSub) {
+            const int np = fQ + delta; // delta < kMtDoubles
+            const bool wrap = np >= kMtDoubles;
+            ctx.setStream(wrap ? fOff ^ kRingStride : fOff, wrap ? np - kMtDoubles : np);
+            ctx.words = 0;
+            ctx.rays = 0;
+            const int uS = myIdx / p.fbV, vS = myIdx - uS * p.fbV;
+            double xu, xv, pd;
+            ctx.draw3(xu, xv, pd);
+            const double ur = static_cast<double>(uS) + xu;
+            const double vr = static_cast<double>(vS) + xv;
+            double u, v;
+            if ((p.uPow2 & p.vPow2) != 0) {
+              u = ur * p.invU;
+              v = vr * p.invV;
+            } else {
+              u = p.uPow2 ? ur * p.invU : ur / static_cast<double>(p.fbU);
+              v = p.vPow2 ? vr * p.invV : vr / static_cast<double>(p.fbV);
+            }
+            d3 nd;
+            const bool refl = scatter(ctx, first, d, u, v, pd, nd);
+            const d3 child = ctx.chainHot(p, first.pos, nd);
+            mine.L[0] = child.x, mine.L[1] = child.y, mine.L[2] = child.z;
+            mine.consumed = static_cast<int>(ctx.words >> 1);
+            mine.refl = refl ? 1 : 0;
+            mine.rays = static_cast<unsigned>(ctx.rays);
+          }
+          SpecResult *slot = results + parity * kSpecWaves;
+          if (lane == 0) slot[wave] = mine;
+          ldsBarrier();
+          // ---- commit (identical in every wave) ----
+          auto commit = [&](int wv) {
+            const SpecResult r = slot[wv];
+            const d3 child = mk(r.L[0], r.L[1], r.L[2]);
+            const bool refl = __builtin_amdgcn_readfirstlane(r.refl) != 0;
+            result = result + (refl ? first.emission + child : first.emission + first.diffuse * child);
+            raysTotal += static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(r.rays)));
+            const int c = __builtin_amdgcn_readfirstlane(r.consumed);
+            if (c != m1) m2 = m1, m1 = c;
+            return c;
+          };
+          // the assignments this round was made with (m1 / m2 change while committing)
+          const int d1 = m1, d2 = oneMode ? 3 * m1 : m2, d3v = 2 * m1;
+          const int i2 = oneMode ? 3 : 1;
+          int cur = commit(0);
+          int nIdx = 1;
+          if (j + nIdx < nSub) {
+            if (d1 == cur) {
+              cur += commit(1);
+              nIdx = 2;
+            } else if (i2 == 1 && d2 == cur) {
+              cur += commit(2);
+              nIdx = 2;
+            }
+          }
+          if (nIdx == 2 && j + nIdx < nSub && d3v == cur) {
+            cur += commit(3);
+            nIdx = 3;
+          }
+          if (nIdx == 3 && j + nIdx < nSub && i2 == 3 && d2 == cur) {
+            cur += commit(2);
+            nIdx = 4;
+          }
+          j += nIdx;
+          sampleDraws += cur;
+          parity ^= 1;
+          advanceFrontier(cur);
+        }
+        L = result * p.invFirstBounce;
+      }
+    }
+    if (threadIdx.x == 0) {
+      myStage[i * 3 + 0] = L.x;
+      myStage[i * 3 + 1] = L.y;
+      myStage[i * 3 + 2] = L.z;
+      if (words) words[static_cast<size_t>(pass) * p.npix + pix] = 2u * static_cast<unsigned>(sampleDraws);
+    }
+  }
+
+  // ---- park the stream for the next band ----
+  __syncthreads();
+  for (int i = threadIdx.x; i < kMtWords; i += kBlock) myState[i] = mt[i];
+  for (int i = threadIdx.x; i < 2 * kRingCanonDoubles; i += kBlock) {
+    const int slot = i / kRingCanonDoubles, k = i - slot * kRingCanonDoubles;
+    myPark[i] = reinterpret_cast<const double *>(ring + slot * kRingStride)[k];
+  }
+  if (threadIdx.x == 0) {
+    myPark[2 * kRingCanonDoubles] = fOff ? 1.0 : 0.0;
+    myPark[2 * kRingCanonDoubles + 1] = static_cast<double>(fQ);
+    if (rayCounters) rayCounters[pass] += raysTotal;
   }
 }
 
@@ -1677,6 +2070,22 @@ hipError_t launchSeqAuto(const TraceParams &p, const TraceBuffers &b, hipStream_
   return launchSeq<SLOTS, WAVES, false>(p, b, stream);
 }
 
+hipError_t launchSeqSpec(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
+  const size_t lds = specLdsBytes(p.ntri, p.nmat, p.nsph);
+  static size_t configured = 0;
+  if (lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(traceSequentialSpec),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    configured = lds;
+  }
+  hipLaunchKernelGGL(traceSequentialSpec, dim3(p.npass), dim3(64 * kSpecWaves), lds, stream, p,
+                     b.triGeom, b.spheres, b.triCompact, b.matTable, b.mtState, b.specState, b.stage,
+                     b.words, b.rays);
+  return hipGetLastError();
+}
+
 } // namespace
 
 hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
@@ -1691,6 +2100,9 @@ hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hi
     const bool reg = !(regEnv && regEnv[0] == '0') && p.nsph <= 64 && p.nsph + n <= 127 &&
                      p.maxDepth <= 9 &&
                      seqLdsBytes(1, p.maxDepth, true, p.ntri, p.nmat, p.nsph) <= kLdsTableBudget;
+    // ... and, by default, with the fan-out traced speculatively by four waves (PTW_SEQ_SPEC=0: off)
+    static const char *specEnv = std::getenv("PTW_SEQ_SPEC");
+    if (reg && !(specEnv && specEnv[0] == '0') && b.specState) return launchSeqSpec(p, b, stream);
     if (reg) return launchSeq<1, 1, true, true>(p, b, stream);
     return launchSeqAuto<1, 1>(p, b, stream);
   }

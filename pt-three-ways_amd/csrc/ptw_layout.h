@@ -56,6 +56,9 @@ constexpr int kMatDoubles = 10;
 
 constexpr int kMtWords = 624;
 constexpr int kMtDoubles = 312; // canonical doubles per regeneration (2 words each)
-constexpr int kMaxDepth = 64;   // radiance stack capacity (levels kept in LDS)
+constexpr int kMaxDepth = 64;
+// traceSequentialSpec parks, per pass: the canonical doubles of both ring slots (2 x 316), the
+// slot and position of the stream frontier.
+constexpr int kSpecStateDoubles = 2 * 316 + 2;   // radiance stack capacity (levels kept in LDS)
 
 } // namespace ptw
