@@ -1227,11 +1227,9 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + 1)) void traceSeque
 // -----------------------------------------------------------------------------------------
 constexpr int kSpecWaves = 4;
 
-struct SpecResult { // one per wave and round parity, in LDS
-  double L[3];      // radiance of the sub-path below the first-bounce surface
-  int consumed;     // canonical doubles the sub-sample consumed
-  int refl;         // lobe taken at the first-bounce surface
-  unsigned rays;    // intersect() calls
+struct alignas(16) SpecResult { // one per wave and round parity, in LDS
+  double L[3]; // radiance of the sub-path below the first-bounce surface
+  int meta;    // canonical doubles consumed | lobe at the first-bounce surface << 8 | rays << 16
   int pad;
 };
 
@@ -1239,6 +1237,7 @@ __host__ __device__ inline size_t specLdsBytes(uint32_t ntri, uint32_t nmat, uin
   size_t n = 2 * kRingStride;                          // the ring
   n += kMtWords * sizeof(uint32_t);                    // raw generator state
   n += 2 * kSpecWaves * sizeof(SpecResult);            // results, double-buffered
+  n += 64;                                             // generator commands
   n = (n + 63) & ~static_cast<size_t>(63);
   n += static_cast<size_t>(nsph) * sizeof(SphereRec);
   n += static_cast<size_t>(ntri) * kTriCompactDoubles * sizeof(double);
@@ -1248,17 +1247,21 @@ __host__ __device__ inline size_t specLdsBytes(uint32_t ntri, uint32_t nmat, uin
   return n < floor ? floor : n;
 }
 
-__global__ __launch_bounds__(64 * kSpecWaves) void traceSequentialSpec(
+// Commands of the tracing waves to the generator wave (one word per barrier parity).
+constexpr uint32_t kGenNone = 0, kGenSlot0 = 1, kGenSlot1 = 2, kGenExit = 3;
+
+__global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
     const TraceParams p, const double *__restrict__ triGeom, const SphereRec *__restrict__ spheres,
     const double *__restrict__ triCompact, const double *__restrict__ matTable,
     uint32_t *__restrict__ mtState, double *__restrict__ specState, double *__restrict__ stage,
     uint32_t *__restrict__ words, unsigned long long *__restrict__ rayCounters) {
   extern __shared__ __attribute__((aligned(64))) unsigned char ldsRaw[];
-  constexpr int kBlock = 64 * kSpecWaves;
+  constexpr int kBlock = 64 * (kSpecWaves + 1);
   char *ring = reinterpret_cast<char *>(ldsRaw);
   uint32_t *mt = reinterpret_cast<uint32_t *>(ldsRaw + 2 * kRingStride);
   SpecResult *results = reinterpret_cast<SpecResult *>(mt + kMtWords);
-  size_t off = 2 * kRingStride + kMtWords * sizeof(uint32_t) + 2 * kSpecWaves * sizeof(SpecResult);
+  volatile uint32_t *genCmd = reinterpret_cast<volatile uint32_t *>(results + 2 * kSpecWaves);
+  size_t off = 2 * kRingStride + kMtWords * sizeof(uint32_t) + 2 * kSpecWaves * sizeof(SpecResult) + 64;
   off = (off + 63) & ~static_cast<size_t>(63);
 
   const int pass = blockIdx.x;
@@ -1294,7 +1297,8 @@ __global__ __launch_bounds__(64 * kSpecWaves) void traceSequentialSpec(
     ctx.tab.tri = lt;
     ctx.tab.mat = lm;
   }
-  ctx.loadPrimitives();
+  const bool isGenerator = wave == kSpecWaves; // the fifth wave only produces the stream
+  if (!isGenerator) ctx.loadPrimitives();
 
   // ---- the stream: resume (or start) this pass's generator ring ----
   uint32_t *myState = mtState + static_cast<size_t>(pass) * kMtWords;
@@ -1304,7 +1308,7 @@ __global__ __launch_bounds__(64 * kSpecWaves) void traceSequentialSpec(
   int fQ = 0;        // ... and position in it
   if (p.firstBand) {
     __syncthreads();
-    if (wave == 0) {
+    if (isGenerator) {
       specGenerateBlock(mt, ring, 0, lane);           // block 0
       specGenerateBlock(mt, ring, kRingStride, lane); // block 1 (completes block 0's overlap)
     }
@@ -1324,17 +1328,43 @@ __global__ __launch_bounds__(64 * kSpecWaves) void traceSequentialSpec(
   }
   __syncthreads();
 
-  // Moves the frontier by n draws; when it enters the other slot, wave 0 generates the block after
-  // it into the slot left behind.  Every wave calls this with the same n at the same point.
-  auto advanceFrontier = [&](int n) {
+  // ---- the generator wave: serves one command per workgroup barrier until told to exit ----
+  if (isGenerator) {
+    for (unsigned k = 0;; ++k) {
+      ldsBarrier();
+      const uint32_t cmd = genCmd[k & 1];
+      if (cmd == kGenExit) break;
+      if (cmd == kGenSlot0) specGenerateBlock(mt, ring, 0, lane);
+      if (cmd == kGenSlot1) specGenerateBlock(mt, ring, kRingStride, lane);
+    }
+  } else {
+  // Stream bookkeeping of the tracing waves (identical in all of them).  When the frontier
+  // enters the other slot, the slot it left is handed to the generator wave with the next
+  // barrier (genState 1 -> 2); the block is complete once the barrier after that has been passed
+  // (2 -> 0), because the generator arrives there only when it is done.  The tracing waves
+  // read at most `ahead` draws beyond the frontier, so they only have to wait for an
+  // outstanding block when the frontier comes that close to the end of its slot.
+  unsigned barriers = 0;
+  int genState = 0;
+  unsigned genSlot = 0;
+  const int ahead = 12 * (p.maxDepth > 0 ? p.maxDepth : 1) + 8;
+  auto roundBarrier = [&](uint32_t exitCmd) {
+    if (threadIdx.x == 0)
+      genCmd[barriers & 1] = exitCmd ? exitCmd : (genState == 1 ? (genSlot ? kGenSlot1 : kGenSlot0) : kGenNone);
+    ldsBarrier();
+    ++barriers;
+    genState = genState == 1 ? 2 : 0;
+  };
+  auto ensureAhead = [&]() {
+    while (genState != 0 && fQ + ahead >= kMtDoubles) roundBarrier(0);
+  };
+  auto advanceFrontier = [&](int n) { // n < kMtDoubles
     const int np = fQ + n;
     if (np >= kMtDoubles) {
-      const unsigned oldOff = fOff;
+      genSlot = fOff; // the slot left behind takes the block after the next
+      genState = 1;
       fQ = np - kMtDoubles;
       fOff ^= kRingStride;
-      ldsBarrier(); // nobody reads the old slot any more
-      if (wave == 0) specGenerateBlock(mt, ring, oldOff, lane);
-      ldsBarrier();
     } else {
       fQ = np;
     }
@@ -1347,12 +1377,18 @@ __global__ __launch_bounds__(64 * kSpecWaves) void traceSequentialSpec(
   unsigned long long raysTotal = 0;
   int m1 = 3 * (p.maxDepth > 0 ? p.maxDepth : 1), m2 = m1; // recent consumption counts (draws)
   int parity = 0;
+#if PTW_PROFILE_PHASES
+  unsigned long long stRounds = 0, stCommits = 0, stWork = 0, stWait = 0, stCommit = 0, stPrimary = 0;
+  const unsigned long long stT0 = __builtin_amdgcn_s_memtime();
+#endif
 
   for (uint32_t i = 0; i < p.pixCount; ++i) {
     const uint32_t pix = p.pixBegin + i;
     const int px = static_cast<int>(pix % static_cast<uint32_t>(w));
     const int py = static_cast<int>(pix / static_cast<uint32_t>(w));
     // ---- every wave: camera ray and first hit at the frontier (redundant, in parallel) ----
+    PTW_T(tP0);
+    ensureAhead();
     ctx.setStream(fOff, fQ);
     double r0, r1, r2 = 0, r3 = 0;
     if (lens) {
@@ -1379,6 +1415,9 @@ __global__ __launch_bounds__(64 * kSpecWaves) void traceSequentialSpec(
       }
     }
     advanceFrontier(camDraws);
+#if PTW_PROFILE_PHASES
+    stPrimary += __builtin_amdgcn_s_memtime() - tP0;
+#endif
     if (traced) {
       const Surface first = ctx.surfaceAt(k0, o, d);
       if (p.preview) {
@@ -1387,6 +1426,7 @@ __global__ __launch_bounds__(64 * kSpecWaves) void traceSequentialSpec(
         d3 result = mk(0, 0, 0);
         int j = 0;
         while (j < nSub) {
+          ensureAhead();
           // ---- this wave's assignment: sub-sample j + ioff, stream position frontier + delta ----
           const bool oneMode = m2 == m1;
           int ioff = 0, delta = 0;
@@ -1394,9 +1434,10 @@ __global__ __launch_bounds__(64 * kSpecWaves) void traceSequentialSpec(
           if (wave == 2) ioff = oneMode ? 3 : 1, delta = oneMode ? 3 * m1 : m2;
           if (wave == 3) ioff = 2, delta = 2 * m1;
           const int myIdx = j + ioff;
+          PTW_T(tW0);
           SpecResult mine;
           mine.L[0] = mine.L[1] = mine.L[2] = 0;
-          mine.consumed = 0, mine.refl = 0, mine.rays = 0, mine.pad = 0;
+          mine.meta = 0, mine.pad = 0;
           if (myIdx < nSub) {
             const int np = fQ + delta; // delta < kMtDoubles
             const bool wrap = np >= kMtDoubles;
@@ -1420,50 +1461,67 @@ __global__ __launch_bounds__(64 * kSpecWaves) void traceSequentialSpec(
             const bool refl = scatter(ctx, first, d, u, v, pd, nd);
             const d3 child = ctx.chainHot(p, first.pos, nd);
             mine.L[0] = child.x, mine.L[1] = child.y, mine.L[2] = child.z;
-            mine.consumed = static_cast<int>(ctx.words >> 1);
-            mine.refl = refl ? 1 : 0;
-            mine.rays = static_cast<unsigned>(ctx.rays);
+            mine.meta = static_cast<int>(ctx.words >> 1) | (refl ? 0x100 : 0) |
+                        (static_cast<int>(ctx.rays) << 16);
           }
           SpecResult *slot = results + parity * kSpecWaves;
           if (lane == 0) slot[wave] = mine;
-          ldsBarrier();
-          // ---- commit (identical in every wave) ----
-          auto commit = [&](int wv) {
-            const SpecResult r = slot[wv];
-            const d3 child = mk(r.L[0], r.L[1], r.L[2]);
-            const bool refl = __builtin_amdgcn_readfirstlane(r.refl) != 0;
-            result = result + (refl ? first.emission + child : first.emission + first.diffuse * child);
-            raysTotal += static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(r.rays)));
-            const int c = __builtin_amdgcn_readfirstlane(r.consumed);
-            if (c != m1) m2 = m1, m1 = c;
-            return c;
-          };
-          // the assignments this round was made with (m1 / m2 change while committing)
+          PTW_T(tW1);
+          roundBarrier(0);
+          PTW_T(tW2);
+          // ---- commit (the scalar part identical in every wave) ----
+          const int metaV = slot[lane & 3].meta;
+          const int meta0 = __builtin_amdgcn_readlane(metaV, 0), meta1 = __builtin_amdgcn_readlane(metaV, 1);
+          const int meta2 = __builtin_amdgcn_readlane(metaV, 2), meta3 = __builtin_amdgcn_readlane(metaV, 3);
+          const int c0 = meta0 & 0xff, c1 = meta1 & 0xff, c2 = meta2 & 0xff, c3 = meta3 & 0xff;
+          // the assignments this round was made with
           const int d1 = m1, d2 = oneMode ? 3 * m1 : m2, d3v = 2 * m1;
-          const int i2 = oneMode ? 3 : 1;
-          int cur = commit(0);
-          int nIdx = 1;
-          if (j + nIdx < nSub) {
-            if (d1 == cur) {
-              cur += commit(1);
-              nIdx = 2;
-            } else if (i2 == 1 && d2 == cur) {
-              cur += commit(2);
-              nIdx = 2;
-            }
-          }
-          if (nIdx == 2 && j + nIdx < nSub && d3v == cur) {
-            cur += commit(3);
-            nIdx = 3;
-          }
-          if (nIdx == 3 && j + nIdx < nSub && i2 == 3 && d2 == cur) {
-            cur += commit(2);
-            nIdx = 4;
+          const bool w2Second = !oneMode; // wave 2 ran sub-sample j+1 (else j+3)
+          const bool more1 = j + 1 < nSub, more2 = j + 2 < nSub, more3 = j + 3 < nSub;
+          const bool ok1 = more1 & (d1 == c0);
+          const bool ok2a = more1 & !ok1 & w2Second & (d2 == c0);
+          const int cur1 = c0 + (ok1 ? c1 : 0) + (ok2a ? c2 : 0);
+          const bool two = ok1 | ok2a;
+          const bool ok3 = two & more2 & (d3v == cur1);
+          const int cur2 = cur1 + (ok3 ? c3 : 0);
+          const bool ok2b = ok3 & more3 & !w2Second & (d2 == cur2);
+          const int cur = cur2 + (ok2b ? c2 : 0);
+          const int nIdx = 1 + (two ? 1 : 0) + (ok3 ? 1 : 0) + (ok2b ? 1 : 0);
+          // most recent / most recent different consumption, in commit order
+          auto note = [&](bool on, int c) {
+            const bool change = on & (c != m1);
+            m2 = change ? m1 : m2;
+            m1 = change ? c : m1;
+          };
+          note(true, c0);
+          note(ok1, c1);
+          note(ok2a, c2);
+          note(ok3, c3);
+          note(ok2b, c2);
+          raysTotal += static_cast<unsigned>(meta0 >> 16) + (ok1 ? static_cast<unsigned>(meta1 >> 16) : 0u) +
+                       ((ok2a | ok2b) ? static_cast<unsigned>(meta2 >> 16) : 0u) +
+                       (ok3 ? static_cast<unsigned>(meta3 >> 16) : 0u);
+          if (wave == 0) { // only the wave that stores the sample needs the radiance
+            auto add = [&](int wv, int meta) {
+              const SpecResult &r = slot[wv];
+              const d3 child = mk(r.L[0], r.L[1], r.L[2]);
+              result = result + ((meta & 0x100) ? first.emission + child
+                                                : first.emission + first.diffuse * child);
+            };
+            add(0, meta0);
+            if (ok1) add(1, meta1);
+            if (ok2a) add(2, meta2);
+            if (ok3) add(3, meta3);
+            if (ok2b) add(2, meta2);
           }
           j += nIdx;
           sampleDraws += cur;
           parity ^= 1;
           advanceFrontier(cur);
+#if PTW_PROFILE_PHASES
+          stRounds++, stCommits += nIdx;
+          stWork += tW1 - tW0, stWait += tW2 - tW1, stCommit += __builtin_amdgcn_s_memtime() - tW2;
+#endif
         }
         L = result * p.invFirstBounce;
       }
@@ -1476,17 +1534,29 @@ __global__ __launch_bounds__(64 * kSpecWaves) void traceSequentialSpec(
     }
   }
 
+  while (genState != 0) roundBarrier(0); // an outstanding block must be in the ring that gets parked
+  roundBarrier(kGenExit);
+#if PTW_PROFILE_PHASES
+  if (pass == 0 && lane == 0) {
+    const double n = static_cast<double>(p.pixCount);
+    printf("SPEC wave %d: cycles/sample=%.0f rounds/sample=%.2f commits/round=%.2f primary=%.0f work=%.0f "
+           "wait=%.0f commit+advance=%.0f (per sample)\n",
+           wave, (__builtin_amdgcn_s_memtime() - stT0) / n, stRounds / n,
+           static_cast<double>(stCommits) / stRounds, stPrimary / n, stWork / n, stWait / n, stCommit / n);
+  }
+#endif
+  if (threadIdx.x == 0) {
+    myPark[2 * kRingCanonDoubles] = fOff ? 1.0 : 0.0;
+    myPark[2 * kRingCanonDoubles + 1] = static_cast<double>(fQ);
+    if (rayCounters) rayCounters[pass] += raysTotal;
+  }
+  } // tracing waves
   // ---- park the stream for the next band ----
   __syncthreads();
   for (int i = threadIdx.x; i < kMtWords; i += kBlock) myState[i] = mt[i];
   for (int i = threadIdx.x; i < 2 * kRingCanonDoubles; i += kBlock) {
     const int slot = i / kRingCanonDoubles, k = i - slot * kRingCanonDoubles;
     myPark[i] = reinterpret_cast<const double *>(ring + slot * kRingStride)[k];
-  }
-  if (threadIdx.x == 0) {
-    myPark[2 * kRingCanonDoubles] = fOff ? 1.0 : 0.0;
-    myPark[2 * kRingCanonDoubles + 1] = static_cast<double>(fQ);
-    if (rayCounters) rayCounters[pass] += raysTotal;
   }
 }
 
@@ -2080,7 +2150,7 @@ hipError_t launchSeqSpec(const TraceParams &p, const TraceBuffers &b, hipStream_
     if (e != hipSuccess) return e;
     configured = lds;
   }
-  hipLaunchKernelGGL(traceSequentialSpec, dim3(p.npass), dim3(64 * kSpecWaves), lds, stream, p,
+  hipLaunchKernelGGL(traceSequentialSpec, dim3(p.npass), dim3(64 * (kSpecWaves + 1)), lds, stream, p,
                      b.triGeom, b.spheres, b.triCompact, b.matTable, b.mtState, b.specState, b.stage,
                      b.words, b.rays);
   return hipGetLastError();
