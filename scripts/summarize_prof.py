@@ -11,7 +11,8 @@ from pathlib import Path
 
 src, dst = Path(sys.argv[1]), Path(sys.argv[2])
 dst.parent.mkdir(parents=True, exist_ok=True)
-OURS = ("traceSequential", "tracePerPixel", "resolveKernel", "intersectBatch", "rngKat")
+OURS = ("traceSequentialSpec", "traceSequential", "tracePerPixelPersistent", "tracePerPixel", "resolveKernel",
+        "intersectBatch", "rngKat")
 
 
 def short(name):

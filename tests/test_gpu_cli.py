@@ -8,9 +8,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def run_cli(pkg, args, cwd):
+def run_cli(pkg, args, cwd, env=None):
+    import os
     exe = pkg.LIB_PATH.parent / "pt_three_ways_hip"
-    proc = subprocess.run([str(exe)] + args, cwd=cwd, capture_output=True, text=True, timeout=300)
+    proc = subprocess.run([str(exe)] + args, cwd=cwd, capture_output=True, text=True, timeout=300,
+                          env=dict(os.environ, **env) if env else None)
     assert proc.returncode == 0, proc.stdout + proc.stderr
     return proc.stdout
 
@@ -52,6 +54,24 @@ def test_chunked_save_every_and_png_and_merge(pkg, tmp_path):
     out = run_cli(pkg, ["-w", "8", "-h", "8", "--spp", "2", "--seed", "7", "--scene", "ce", "--save-every", "0",
                         str(tmp_path / "ce.png")], ROOT)
     assert "Scene contains 3442 triangles and 3 spheres." in out
+
+
+@pytest.mark.parametrize("scene,extra", [
+    ("cornell", []), ("single-sphere", ["--max-depth", "3"]), ("cornell", ["--first-bounce-u", "3", "--first-bounce-v", "5"]),
+])
+def test_sequential_kernel_variants_write_identical_bytes(pkg, tmp_path, scene, extra):
+    """The speculative four-wave kernel, the single-wave register-stack kernel and the plain
+    single-wave kernel are three schedules of one computation: same .raw bytes.  A tiny staging
+    budget makes every pass park and resume its stream dozens of times."""
+    from conftest import ROOT
+    args = ["-w", "40", "-h", "28", "--spp", "5", "--seed", "11", "--scene", scene, "--raw", "--save-every", "0"] + extra
+    variants = {"spec": {}, "reg": {"PTW_SEQ_SPEC": "0"}, "plain": {"PTW_SEQ_SPEC": "0", "PTW_SEQ_REG": "0"},
+                "spec_bands": {"PTW_STAGE_BUDGET_KB": "12"}}
+    blobs = {}
+    for name, env in variants.items():
+        run_cli(pkg, args + [str(tmp_path / f"{name}.raw")], ROOT, env=env)
+        blobs[name] = (tmp_path / f"{name}.raw").read_bytes()
+    assert blobs["spec"] == blobs["reg"] == blobs["plain"] == blobs["spec_bands"]
 
 
 def test_cli_errors(pkg, tmp_path):
