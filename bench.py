@@ -192,6 +192,9 @@ def main():
         achieved_tflops = rays_per_launch * flop_per_ray / avg_launch_s / 1e12
         hbm_gbs = samples_per_launch * HBM_BYTES_PER_SAMPLE_TRACE / avg_launch_s / 1e9
         kernel = "traceSequential" if policy == pkg.RNG_SEQUENTIAL else "tracePerPixel"
+        kernel_variant = kernel
+        if policy == pkg.RNG_SEQUENTIAL and ntri <= 64 and nsph <= 64 and os.environ.get("PTW_SEQ_SPEC", "1") != "0":
+            kernel_variant = "traceSequentialSpec"  # the variant launchTraceSequential() picks (ptw_kernels.hip)
         traffic = None
         traffic_file = ROOT / "profiles" / "hbm_traffic.json"
         if traffic_file.exists():
@@ -216,7 +219,7 @@ def main():
                                if world > 1 else "single GPU",
             },
             "roofline": {
-                "bound": "valu_fp64", "kernel": kernel,
+                "bound": "valu_fp64", "kernel": kernel_variant,
                 "achieved": achieved_tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tflops / FP64_VALU_PEAK_TFLOPS,
                 "traffic": traffic,
