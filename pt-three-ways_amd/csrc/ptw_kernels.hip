@@ -1375,10 +1375,15 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
   const int nSub = p.fbU * p.fbV;
   double *myStage = stage + static_cast<size_t>(pass) * p.pixCount * 3;
   unsigned long long raysTotal = 0;
-  int m1 = 3 * (p.maxDepth > 0 ? p.maxDepth : 1), m2 = m1; // recent consumption counts (draws)
+  // The guesses: m1 = the most frequent count of draws a sub-sample has consumed so far in this
+  // pass (3 per level reached), m2 = the second most frequent (m2 == m1 while only one value has
+  // been seen).  `hist` counts them in 6-bit fields, halved when a field passes 31.
+  int m1 = 3 * (p.maxDepth > 0 ? p.maxDepth : 1), m2 = m1;
+  unsigned long long hist = 0;
   int parity = 0;
 #if PTW_PROFILE_PHASES
   unsigned long long stRounds = 0, stCommits = 0, stWork = 0, stWait = 0, stCommit = 0, stPrimary = 0;
+  unsigned long long stOk1 = 0, stOk2a = 0, stOk3 = 0, stOk2b = 0, stIdle = 0;
   const unsigned long long stT0 = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -1425,6 +1430,22 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
       } else {
         d3 result = mk(0, 0, 0);
         int j = 0;
+        if (hist != 0) { // refresh the guesses once per sample
+          if (hist & 0x0820820820820820ull) hist = (hist >> 1) & 0x07df7df7df7df7dfull;
+          int best = 0, bestN = -1, second = 0, secondN = 0;
+#pragma unroll
+          for (int f = 1; f <= 9; ++f) {
+            const int n = static_cast<int>(hist >> (6 * f)) & 63;
+            const bool top = n > bestN;
+            const bool sec = !top & (n > secondN);
+            second = top ? best : (sec ? f : second);
+            secondN = top ? bestN : (sec ? n : secondN);
+            best = top ? f : best;
+            bestN = top ? n : bestN;
+          }
+          m1 = 3 * best;
+          m2 = secondN > 0 ? 3 * second : m1;
+        }
         while (j < nSub) {
           ensureAhead();
           // ---- this wave's assignment: sub-sample j + ioff, stream position frontier + delta ----
@@ -1487,11 +1508,9 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
           const bool ok2b = ok3 & more3 & !w2Second & (d2 == cur2);
           const int cur = cur2 + (ok2b ? c2 : 0);
           const int nIdx = 1 + (two ? 1 : 0) + (ok3 ? 1 : 0) + (ok2b ? 1 : 0);
-          // most recent / most recent different consumption, in commit order
+          // histogram of the committed counts (6-bit fields indexed by count / 3)
           auto note = [&](bool on, int c) {
-            const bool change = on & (c != m1);
-            m2 = change ? m1 : m2;
-            m1 = change ? c : m1;
+            hist += on ? 1ull << (6 * ((c * 11) >> 5)) : 0ull;
           };
           note(true, c0);
           note(ok1, c1);
@@ -1520,6 +1539,7 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
           advanceFrontier(cur);
 #if PTW_PROFILE_PHASES
           stRounds++, stCommits += nIdx;
+          stOk1 += ok1, stOk2a += ok2a, stOk3 += ok3, stOk2b += ok2b, stIdle += !(myIdx < nSub);
           stWork += tW1 - tW0, stWait += tW2 - tW1, stCommit += __builtin_amdgcn_s_memtime() - tW2;
 #endif
         }
@@ -1543,6 +1563,9 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
            "wait=%.0f commit+advance=%.0f (per sample)\n",
            wave, (__builtin_amdgcn_s_memtime() - stT0) / n, stRounds / n,
            static_cast<double>(stCommits) / stRounds, stPrimary / n, stWork / n, stWait / n, stCommit / n);
+    printf("SPEC wave %d: per round ok1=%.3f ok2a=%.3f ok3=%.3f ok2b=%.3f idle=%.3f\n", wave,
+           (double)stOk1 / stRounds, (double)stOk2a / stRounds, (double)stOk3 / stRounds,
+           (double)stOk2b / stRounds, (double)stIdle / stRounds);
   }
 #endif
   if (threadIdx.x == 0) {
