@@ -1373,6 +1373,7 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
   const int w = p.width;
   const bool lens = p.cam.aperture_radius != 0;
   const int nSub = p.fbU * p.fbV;
+  const int vShift = p.fbV > 0 ? 31 - __builtin_clz(static_cast<unsigned>(p.fbV)) : 0;
   double *myStage = stage + static_cast<size_t>(pass) * p.pixCount * 3;
   unsigned long long raysTotal = 0;
   // The guesses: m1 = the most frequent count of draws a sub-sample has consumed so far in this
@@ -1465,7 +1466,9 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
             ctx.setStream(wrap ? fOff ^ kRingStride : fOff, wrap ? np - kMtDoubles : np);
             ctx.words = 0;
             ctx.rays = 0;
-            const int uS = myIdx / p.fbV, vS = myIdx - uS * p.fbV;
+            // sub-sample index -> stratum (uS, vS); a shift when fbV is a power of two
+            const int uS = p.vPow2 ? myIdx >> vShift : myIdx / p.fbV;
+            const int vS = myIdx - uS * p.fbV;
             double xu, xv, pd;
             ctx.draw3(xu, xv, pd);
             const double ur = static_cast<double>(uS) + xu;
@@ -2135,7 +2138,7 @@ __global__ __launch_bounds__(64) void rngKatKernel(int rngPolicy,
   }
 }
 
-constexpr size_t kLdsTableBudget = 96 * 1024; // bytes of LDS we are willing to spend on tables
+constexpr size_t kLdsTableBudget = 150 * 1024; // bytes of LDS we are willing to spend on tables
 
 template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false>
 hipError_t launchSeq(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
