@@ -2197,8 +2197,20 @@ hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hi
                      p.maxDepth <= 9 &&
                      seqLdsBytes(1, p.maxDepth, true, p.ntri, p.nmat, p.nsph) <= kLdsTableBudget;
     // ... and, by default, with the fan-out traced speculatively by four waves (PTW_SEQ_SPEC=0: off)
+    // The speculative kernel spends a whole CU on a pass.  That pays while there are at most as many
+    // passes as CUs; with more, one wave per pass on every SIMD is the better use of the chip.
     static const char *specEnv = std::getenv("PTW_SEQ_SPEC");
-    if (reg && !(specEnv && specEnv[0] == '0') && b.specState) return launchSeqSpec(p, b, stream);
+    static int cus = 0;
+    if (cus == 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    }
+    const bool forced = specEnv && specEnv[0] == '2'; // PTW_SEQ_SPEC=2: whatever the pass count
+    if (reg && !(specEnv && specEnv[0] == '0') && b.specState &&
+        (forced || p.npass <= static_cast<uint32_t>(cus)))
+      return launchSeqSpec(p, b, stream);
     if (reg) return launchSeq<1, 1, true, true>(p, b, stream);
     return launchSeqAuto<1, 1>(p, b, stream);
   }
