@@ -1260,7 +1260,10 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
   char *ring = reinterpret_cast<char *>(ldsRaw);
   uint32_t *mt = reinterpret_cast<uint32_t *>(ldsRaw + 2 * kRingStride);
   SpecResult *results = reinterpret_cast<SpecResult *>(mt + kMtWords);
-  volatile uint32_t *genCmd = reinterpret_cast<volatile uint32_t *>(results + 2 * kSpecWaves);
+  // (taken from ldsRaw inside the lambdas too: a captured pointer loses its LDS address space and
+  // the stores turn into flat instructions with a vmcnt wait)
+  constexpr size_t kGenCmdOffset = 2 * kRingStride + kMtWords * sizeof(uint32_t) + 2 * kSpecWaves * sizeof(SpecResult);
+  uint32_t *genCmd = reinterpret_cast<uint32_t *>(ldsRaw + kGenCmdOffset);
   size_t off = 2 * kRingStride + kMtWords * sizeof(uint32_t) + 2 * kSpecWaves * sizeof(SpecResult) + 64;
   off = (off + 63) & ~static_cast<size_t>(63);
 
@@ -1350,7 +1353,8 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
   const int ahead = 12 * (p.maxDepth > 0 ? p.maxDepth : 1) + 8;
   auto roundBarrier = [&](uint32_t exitCmd) {
     if (threadIdx.x == 0)
-      genCmd[barriers & 1] = exitCmd ? exitCmd : (genState == 1 ? (genSlot ? kGenSlot1 : kGenSlot0) : kGenNone);
+      reinterpret_cast<uint32_t *>(ldsRaw + kGenCmdOffset)[barriers & 1] =
+          exitCmd ? exitCmd : (genState == 1 ? (genSlot ? kGenSlot1 : kGenSlot0) : kGenNone);
     ldsBarrier();
     ++barriers;
     genState = genState == 1 ? 2 : 0;
