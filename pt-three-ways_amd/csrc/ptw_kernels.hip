@@ -1,27 +1,39 @@
 // ptw_kernels.hip — hand-written HIP kernels (gfx950, wave64) for pt-three-ways' DoD radiance
 // path: dod::Scene::render -> radiance -> intersect* (src/dod/Scene.cpp).
 //
-// Two kernels trace, one accumulates:
+// Kernels (launchTraceSequential / launchTracePerPixel pick the variant):
 //
-//  traceSequential<SLOTS, WAVES>   SEQUENTIAL RNG policy (bit-compatible with the reference's
-//      per-pass std::mt19937 stream).  Within a pass the reference consumes one RNG stream
-//      across pixels in row-major order with a data-dependent number of draws per pixel
-//      (Scene.cpp:211-217), so pixels of one pass are serially dependent.  Parallelism is
+//  traceSequential<SLOTS, WAVES, LDS_TABLES, REG>   SEQUENTIAL RNG policy (bit-compatible with
+//      the reference's per-pass std::mt19937 stream).  Within a pass the reference consumes one
+//      RNG stream across pixels in row-major order with a data-dependent number of draws per
+//      pixel (Scene.cpp:211-217), so pixels of one pass are serially dependent.  Parallelism is
 //      therefore (a) across passes: ONE WORKGROUP PER PASS, and (b) inside a ray's brute-force
 //      nearest-hit search: every lane owns SLOTS triangles, resident in VGPRs for the whole
 //      launch (v0, e1, e2 as 9 doubles each; zero memory traffic in the hot loop), tests them
-//      against the wave-uniform ray, and a DPP min-reduction (plus one LDS exchange when
-//      WAVES > 1) picks the nearest hit with the reference's tie-break (lowest insertion
-//      index; spheres before triangles).  Everything after the reduction (shading, sampling,
-//      RNG) is workgroup-uniform.  mt19937 lives in LDS: 624 raw words plus the 312 canonical
-//      doubles they yield, regenerated 64 lanes at a time, so a draw is one LDS broadcast read.
+//      against the wave-uniform ray, and the nearest hit is picked with the reference's
+//      tie-break (lowest insertion index; spheres before triangles).  WAVES == 1: one wave does
+//      everything (scenes up to 128 triangles; REG: the issue-slot-lean variant for up to 64).
+//      WAVES == 7: worker waves hold the primitives, a master wave without primitives runs the
+//      path logic and exchanges ray / nearest hit with them through LDS.  Everything after the
+//      pick (shading, sampling, RNG) is wave-uniform.  mt19937 lives in LDS: 624 raw words plus
+//      the 312 canonical doubles and the draw-derived hemisphere table they yield, regenerated
+//      64 lanes at a time, so a draw is one LDS broadcast read.
 //
-//  tracePerPixel                   PERPIXEL policy: one lane per (pass, pixel) sample, sfc32
-//      stream per sample, triangles streamed wave-uniformly (scalar loads, SGPR operands).
+//  traceSequentialSpec          the same policy for scenes up to 64 triangles with the
+//      first-bounce fan-out traced speculatively by four waves against a two-block stream ring
+//      that a fifth wave keeps filled (the headline kernel; see the comment at the kernel).
 //
-//  resolve                         adds the staged per-pass radiance into the fp64 running
-//      sums in pass order (ArrayOutput::operator+=, src/util/ArrayOutput.cpp:48-56) so the
-//      accumulation order - and therefore the rounding - is that of `--max-cpus 1`.
+//  tracePerPixel, tracePerPixelPersistent   PERPIXEL policy: one lane per (pass, pixel) sample,
+//      sfc32 stream per sample, triangles streamed wave-uniformly (scalar loads, SGPR operands);
+//      the persistent form (scenes from 128 triangles) hands samples out through a device-wide
+//      queue so lanes whose paths end early do not idle.
+//
+//  resolveKernel                adds the staged per-pass radiance into the fp64 running sums in
+//      pass order (ArrayOutput::operator+=, src/util/ArrayOutput.cpp:48-56) so the accumulation
+//      order - and therefore the rounding - is that of `--max-cpus 1`.
+//
+//  intersectBatchKernel, rngKatKernel   known-answer entry points (ptw_context_intersect /
+//      ptw_context_rng_doubles).
 #include "ptw_device.h"
 #include "ptw_kernels.h"
 
