@@ -284,6 +284,38 @@ def test_kernel_variants_on_random_soups(pkg, ob, ntri, nsph, policy):
     assert rel_err(rgb, ref_rgb) < TOL
 
 
+# The speculative sequential kernel (scenes up to 64 triangles, depth up to 9): mixed materials,
+# open and closed scenes, every depth, odd fan-outs, several bands.
+@pytest.mark.parametrize("ntri,nsph,shell,over", [
+    (1, 0, True, dict()), (7, 2, True, dict(max_depth=9)), (64, 0, False, dict(max_depth=3)),
+    (40, 20, True, dict(first_bounce_u=5, first_bounce_v=3)), (33, 62, False, dict(max_depth=8, first_bounce_u=2, first_bounce_v=2)),
+    (64, 62, True, dict(max_depth=4, first_bounce_u=1, first_bounce_v=7)), (20, 1, True, dict(max_depth=10)),
+])
+def test_speculative_kernel_on_small_soups(pkg, ob, ntri, nsph, shell, over, monkeypatch):
+    monkeypatch.setenv("PTW_STAGE_BUDGET_KB", "40")  # park / resume the stream ring between bands
+    rng = np.random.default_rng(1000 + ntri)
+    scene = pkg.Scene()
+    mats = [pkg.material("diffuse", rng.uniform(0.2, 0.9, 3)), pkg.material("light", rng.uniform(0.5, 3.0, 3)),
+            pkg.material("glossy", rng.uniform(0.2, 0.9, 3), 1.3, 20.0),
+            pkg.material("reflective", rng.uniform(0.2, 0.9, 3), 0.5, 4.0),
+            pkg.material("specular", rng.uniform(0.2, 0.9, 3), 1.0)]
+    for i in range(ntri):
+        c = rng.uniform(-2, 2, 3)
+        v = c + rng.uniform(-1.5, 1.5, (3, 3))
+        scene.add_triangle(v[0], v[1], v[2], mats[i % len(mats)])
+    for i in range(nsph):
+        scene.add_sphere(rng.uniform(-3, 3, 3), rng.uniform(0.1, 0.8), mats[(i + 2) % len(mats)])
+    if shell:
+        scene.add_sphere((0, 0, 0), 12.0, mats[0])
+    scene.set_environment_colour((0.3, 0.2, 0.1))
+    cam = pkg.set_focus(pkg.look_at((0, 0.5, 7), (0, 0, 0), (0, 1, 0), 24, 16, 45.0), (0, 0, 0), 0.02)
+    params = pkg.default_params(width=24, height=16, samples_per_pixel=5, seed=77, **over)
+    ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(scene.view(), cam, params, threads=4)
+    rgb, cnt, words = gpu_render_with_words(pkg, scene, cam, params)
+    assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words)
+    assert rel_err(rgb, ref_rgb) < TOL
+
+
 # ---- edge cases -------------------------------------------------------------------------------
 @pytest.mark.parametrize("policy", [0, 1])
 def test_edge_cases(pkg, ob, policy):
