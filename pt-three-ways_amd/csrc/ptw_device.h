@@ -117,9 +117,6 @@ __device__ __forceinline__ d3 reflect(d3 n, d3 incoming) {
 // passed in (the host precomputes 1/ior with the same correctly rounded division).
 __device__ __forceinline__ double reflectance(d3 n, d3 incoming, double iorFrom, double iorTo,
                                               double iorRatio) {
-#if PTW_ABLATE == 2
-  return 0.0 * iorFrom * iorTo * iorRatio * dot(n, incoming);
-#endif
   const double cosThetaI = -dot(n, incoming);
   const double sinThetaTSquared = iorRatio * iorRatio * (1 - cosThetaI * cosThetaI);
   if (sinThetaTSquared > 1) return 1.0;
@@ -180,22 +177,11 @@ __device__ __forceinline__ d3 normalisedNearUnit(d3 a) {
 }
 
 // hemisphereSample, src/math/Samples.cpp:21-30
-#ifndef PTW_ABLATE
-#define PTW_ABLATE 0 // timing experiments only: 1 = no sincos, 2 = no reflectance, 3 = no sqrt in sampling
-#endif
 __device__ __forceinline__ d3 hemisphereSample(const Basis &basis, double u, double v) {
   const double theta = (2 * kPi) * u;
-#if PTW_ABLATE == 3
-  const double radius = v;
-#else
   const double radius = sqrtPos(v);
-#endif
   double s, c;
-#if PTW_ABLATE == 1
-  s = theta * 0.1; c = 1.0 - s;
-#else
   sinCos<true>(theta, s, c); // u is a (stratified) canonical draw: theta in [0, 2 pi)
-#endif
   // (c r, s r, sqrt(1 - v)) has squared length v + (1 - v) and the basis is orthonormal, so the
   // transformed vector is unit length up to a few ulp
   return normalisedNearUnit(transform(basis, mk(c * radius, s * radius, sqrtPos(1 - v))));
