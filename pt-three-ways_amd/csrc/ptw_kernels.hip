@@ -476,6 +476,7 @@ struct SeqCtx {
   SeqCommand *cmd;       // master -> workers (WAVES > 1)
   int tid;               // index among the primitive-holding lanes (workers); master: lane id
   int pos;               // next canonical double in sh->canon (wave-uniform)
+  d3 envColour;          // chainHot: the environment colour, kept in vector registers
   char *ringBase;        // SPEC: LDS address of ring slot 0
   unsigned ringOff;      // SPEC: 0 or kRingStride - the slot `pos` indexes
   unsigned words;        // RNG words consumed by the current sample
@@ -980,7 +981,7 @@ struct SeqCtx {
       }
       // ---- general path: miss, last level, sphere, reflective lobe, straddling draws ----
       if (uniformBool(k.idx == kMiss)) { // Scene.cpp:131-133
-        L = ld3(tp.env);
+        L = envColour;
         break;
       }
       if (depth + 1 >= maxDepth) { // last level: see radianceChain()
@@ -1112,6 +1113,8 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + 1)) void traceSeque
   ctx.triCompactGlobal = triCompact;
   ctx.matTableGlobal = matTable;
   ctx.p = &p;
+  ctx.envColour = ld3(p.env);
+  asm volatile("" : "+v"(ctx.envColour.x), "+v"(ctx.envColour.y), "+v"(ctx.envColour.z));
   ctx.triGeom = triGeom;
   ctx.spheresGlobal = spheres;
   ctx.sh = &sh;
@@ -1288,6 +1291,8 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
   ctx.triCompactGlobal = triCompact;
   ctx.matTableGlobal = matTable;
   ctx.p = &p;
+  ctx.envColour = ld3(p.env);
+  asm volatile("" : "+v"(ctx.envColour.x), "+v"(ctx.envColour.y), "+v"(ctx.envColour.z));
   ctx.triGeom = triGeom;
   ctx.spheresGlobal = spheres;
   ctx.sh = nullptr;
