@@ -1395,6 +1395,12 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
   const bool lens = p.cam.aperture_radius != 0;
   const int nSub = p.fbU * p.fbV;
   const int vShift = p.fbV > 0 ? 31 - __builtin_clz(static_cast<unsigned>(p.fbV)) : 0;
+  // Per-round constants in vector registers: as kernel arguments they sit in a 16-register
+  // scalar tuple that does not survive the rounds and would be re-read from its spill lanes
+  // (eighteen v_readlane) for every sub-sample.
+  double invU = p.invU, invV = p.invV;
+  asm volatile("" : "+v"(invU), "+v"(invV));
+  const bool fastFan = (p.uPow2 & p.vPow2) != 0;
   double *myStage = stage + static_cast<size_t>(pass) * p.pixCount * 3;
   unsigned long long raysTotal = 0;
   // The guesses: m1 = the most frequent count of draws a sub-sample has consumed so far in this
@@ -1495,12 +1501,12 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
             const double ur = static_cast<double>(uS) + xu;
             const double vr = static_cast<double>(vS) + xv;
             double u, v;
-            if ((p.uPow2 & p.vPow2) != 0) {
-              u = ur * p.invU;
-              v = vr * p.invV;
+            if (fastFan) {
+              u = ur * invU;
+              v = vr * invV;
             } else {
-              u = p.uPow2 ? ur * p.invU : ur / static_cast<double>(p.fbU);
-              v = p.vPow2 ? vr * p.invV : vr / static_cast<double>(p.fbV);
+              u = p.uPow2 ? ur * invU : ur / static_cast<double>(p.fbU);
+              v = p.vPow2 ? vr * invV : vr / static_cast<double>(p.fbV);
             }
             d3 nd;
             const bool refl = scatter(ctx, first, d, u, v, pd, nd);
