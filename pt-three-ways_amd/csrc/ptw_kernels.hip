@@ -1401,6 +1401,7 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
   double invU = p.invU, invV = p.invV;
   asm volatile("" : "+v"(invU), "+v"(invV));
   const bool fastFan = (p.uPow2 & p.vPow2) != 0;
+  const int vMask = p.fbV - 1;
   double *myStage = stage + static_cast<size_t>(pass) * p.pixCount * 3;
   unsigned long long raysTotal = 0;
   // The guesses: m1 = the most frequent count of draws a sub-sample has consumed so far in this
@@ -1493,18 +1494,18 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
             ctx.setStream(wrap ? fOff ^ kRingStride : fOff, wrap ? np - kMtDoubles : np);
             ctx.words = 0;
             ctx.rays = 0;
-            // sub-sample index -> stratum (uS, vS); a shift when fbV is a power of two
-            const int uS = p.vPow2 ? myIdx >> vShift : myIdx / p.fbV;
-            const int vS = myIdx - uS * p.fbV;
+            // sub-sample index -> stratum (uS, vS) -> stratified (u, v); ONE decision for the
+            // usual power-of-two fan-outs (shift / mask / multiply), the general case apart
             double xu, xv, pd;
             ctx.draw3(xu, xv, pd);
-            const double ur = static_cast<double>(uS) + xu;
-            const double vr = static_cast<double>(vS) + xv;
             double u, v;
             if (fastFan) {
-              u = ur * invU;
-              v = vr * invV;
+              const int uS = myIdx >> vShift, vS = myIdx & vMask;
+              u = (static_cast<double>(uS) + xu) * invU;
+              v = (static_cast<double>(vS) + xv) * invV;
             } else {
+              const int uS = myIdx / p.fbV, vS = myIdx - uS * p.fbV;
+              const double ur = static_cast<double>(uS) + xu, vr = static_cast<double>(vS) + xv;
               u = p.uPow2 ? ur * invU : ur / static_cast<double>(p.fbU);
               v = p.vPow2 ? vr * invV : vr / static_cast<double>(p.fbV);
             }
