@@ -1526,31 +1526,34 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
           const int meta0 = __builtin_amdgcn_readlane(metaV, 0), meta1 = __builtin_amdgcn_readlane(metaV, 1);
           const int meta2 = __builtin_amdgcn_readlane(metaV, 2), meta3 = __builtin_amdgcn_readlane(metaV, 3);
           const int c0 = meta0 & 0xff, c1 = meta1 & 0xff, c2 = meta2 & 0xff, c3 = meta3 & 0xff;
-          // the assignments this round was made with
+          // The assignments this round was made with, and which of them held - as all-ones /
+          // zero integer masks in scalar registers (conditions kept as C++ bools become lane masks
+          // that take a trip through a vector register per use).
+          auto eq = [](int a, int b) { return ((a ^ b) - 1) >> 31; };  // a, b >= 0: -1 if equal
+          auto lt = [](int a, int b) { return (a - b) >> 31; };        // -1 if a < b
           const int d1 = m1, d2 = oneMode ? 3 * m1 : m2, d3v = 2 * m1;
-          const bool w2Second = !oneMode; // wave 2 ran sub-sample j+1 (else j+3)
-          const bool more1 = j + 1 < nSub, more2 = j + 2 < nSub, more3 = j + 3 < nSub;
-          const bool ok1 = more1 & (d1 == c0);
-          const bool ok2a = more1 & !ok1 & w2Second & (d2 == c0);
-          const int cur1 = c0 + (ok1 ? c1 : 0) + (ok2a ? c2 : 0);
-          const bool two = ok1 | ok2a;
-          const bool ok3 = two & more2 & (d3v == cur1);
-          const int cur2 = cur1 + (ok3 ? c3 : 0);
-          const bool ok2b = ok3 & more3 & !w2Second & (d2 == cur2);
-          const int cur = cur2 + (ok2b ? c2 : 0);
-          const int nIdx = 1 + (two ? 1 : 0) + (ok3 ? 1 : 0) + (ok2b ? 1 : 0);
+          const int w2Second = oneMode ? 0 : -1; // wave 2 ran sub-sample j+1 (else j+3)
+          const int ok1 = lt(j + 1, nSub) & eq(d1, c0);
+          const int ok2a = lt(j + 1, nSub) & ~ok1 & w2Second & eq(d2, c0);
+          const int cur1 = c0 + (c1 & ok1) + (c2 & ok2a);
+          const int two = ok1 | ok2a;
+          const int ok3 = two & lt(j + 2, nSub) & eq(d3v, cur1);
+          const int cur2 = cur1 + (c3 & ok3);
+          const int ok2b = ok3 & lt(j + 3, nSub) & ~w2Second & eq(d2, cur2);
+          const int cur = cur2 + (c2 & ok2b);
+          const int nIdx = 1 - two - ok3 - ok2b;
           // histogram of the committed counts (6-bit fields indexed by count / 3)
-          auto note = [&](bool on, int c) {
-            hist += on ? 1ull << (6 * ((c * 11) >> 5)) : 0ull;
+          auto note = [&](int on, int c) {
+            hist += (1ull << (6 * ((c * 11) >> 5))) & static_cast<unsigned long long>(static_cast<long long>(on));
           };
-          note(true, c0);
+          note(-1, c0);
           note(ok1, c1);
           note(ok2a, c2);
           note(ok3, c3);
           note(ok2b, c2);
-          raysTotal += static_cast<unsigned>(meta0 >> 16) + (ok1 ? static_cast<unsigned>(meta1 >> 16) : 0u) +
-                       ((ok2a | ok2b) ? static_cast<unsigned>(meta2 >> 16) : 0u) +
-                       (ok3 ? static_cast<unsigned>(meta3 >> 16) : 0u);
+          raysTotal += static_cast<unsigned>(meta0 >> 16) + (static_cast<unsigned>(meta1 >> 16) & ok1) +
+                       (static_cast<unsigned>(meta2 >> 16) & (ok2a | ok2b)) +
+                       (static_cast<unsigned>(meta3 >> 16) & ok3);
           if (wave == 0) { // only the wave that stores the sample needs the radiance
             auto add = [&](int wv, int meta) {
               const SpecResult &r = slot[wv];
@@ -1570,7 +1573,7 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
           advanceFrontier(cur);
 #if PTW_PROFILE_PHASES
           stRounds++, stCommits += nIdx;
-          stOk1 += ok1, stOk2a += ok2a, stOk3 += ok3, stOk2b += ok2b, stIdle += !(myIdx < nSub);
+          stOk1 -= ok1, stOk2a -= ok2a, stOk3 -= ok3, stOk2b -= ok2b, stIdle += !(myIdx < nSub);
           stWork += tW1 - tW0, stWait += tW2 - tW1, stCommit += __builtin_amdgcn_s_memtime() - tW2;
 #endif
         }
