@@ -278,6 +278,10 @@ __device__ __forceinline__ d3 radiance0(CTX &ctx, const TraceParams &p, const Tr
   const Surface s = ctx.surfaceAt(k, o, d);
   if (p.preview) return s.diffuse; // Scene.cpp:137-138
   d3 result = mk(0, 0, 0);
+  // in vector registers for the fan-out loop (as scalars they would be re-read from the spill
+  // lanes of the kernel-argument tuple for every sub-sample)
+  double invU = p.invU, invV = p.invV;
+  asm volatile("" : "+v"(invU), "+v"(invV));
   for (int uS = 0; uS < p.fbU; ++uS) {
     for (int vS = 0; vS < p.fbV; ++vS) {
       // (double(uSample) + unit(rng)) / double(numUSamples): a power-of-two divisor is an exact
@@ -289,11 +293,11 @@ __device__ __forceinline__ d3 radiance0(CTX &ctx, const TraceParams &p, const Tr
       const double vr = static_cast<double>(vS) + xv;
       double u, v;
       if ((p.uPow2 & p.vPow2) != 0) { // one decision for the usual 4x4 / 2x2 / 1x1 fan-outs
-        u = ur * p.invU;
-        v = vr * p.invV;
+        u = ur * invU;
+        v = vr * invV;
       } else {
-        u = p.uPow2 ? ur * p.invU : ur / static_cast<double>(p.fbU);
-        v = p.vPow2 ? vr * p.invV : vr / static_cast<double>(p.fbV);
+        u = p.uPow2 ? ur * invU : ur / static_cast<double>(p.fbU);
+        v = p.vPow2 ? vr * invV : vr / static_cast<double>(p.fbV);
       }
       d3 nd;
       const bool refl = scatter(ctx, s, d, u, v, pd, nd);
