@@ -316,6 +316,19 @@ def test_speculative_kernel_on_small_soups(pkg, ob, ntri, nsph, shell, over, mon
     assert rel_err(rgb, ref_rgb) < TOL
 
 
+def test_full_width_strip_matches_oracle(pkg, ob):
+    """The headline frame's width (1024) with a few rows: the same pixel -> (x, y) mapping, stream
+    lengths of tens of thousands of generator blocks per pass, several bands."""
+    w, h, spp = 1024, 40, 3
+    scene = pkg.Scene()
+    cam = scene.build_named("cornell", w, h)
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=1)
+    ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(scene.view(), cam, params, threads=3)
+    rgb, cnt, words = gpu_render_with_words(pkg, scene, cam, params)
+    assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words)
+    assert rel_err(rgb, ref_rgb) < TOL
+
+
 # ---- edge cases -------------------------------------------------------------------------------
 @pytest.mark.parametrize("policy", [0, 1])
 def test_edge_cases(pkg, ob, policy):
