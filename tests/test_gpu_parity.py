@@ -316,6 +316,21 @@ def test_speculative_kernel_on_small_soups(pkg, ob, ntri, nsph, shell, over, mon
     assert rel_err(rgb, ref_rgb) < TOL
 
 
+@pytest.mark.parametrize("name,w,h,spp", [("cornell", 96, 96, 64), ("suzanne", 48, 48, 64)])
+def test_repeated_renders_are_bytewise_identical(pkg, name, w, h, spp):
+    """The sequential kernels pass data between waves through LDS; a race would show up as a run
+    that differs (scripts/stress_determinism.py is the longer form of this)."""
+    scene = pkg.Scene()
+    cam = scene.build_named(name, w, h)
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=9)
+    first = None
+    for _ in range(4):
+        rgb, cnt, words = gpu_render_with_words(pkg, scene, cam, params)
+        blob = rgb.tobytes() + words.tobytes()
+        first = first or blob
+        assert blob == first
+
+
 def test_full_width_strip_matches_oracle(pkg, ob):
     """The headline frame's width (1024) with a few rows: the same pixel -> (x, y) mapping, stream
     lengths of tens of thousands of generator blocks per pass, several bands."""
