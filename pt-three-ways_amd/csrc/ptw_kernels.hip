@@ -451,7 +451,7 @@ struct SeqCtx {
   // surface record that way was measured and is slower: one ds_read_b128 moves what four
   // v_readlane do.)
   static_assert(!REG || (SLOTS == 1 && WAVES == 1), "REG needs one wave and one triangle per lane");
-  double rec[REG ? kRecDoubles : 1];
+  double rec[kRecDoubles]; // REG only (never touched otherwise, so it costs nothing there)
   unsigned long long stackBits; // REG: level i in bits [8i, 8i+8): combined index | lobe << 7
   unsigned long long emissiveMask; // REG: lanes whose triangle has a non-zero emission
 
