@@ -2179,13 +2179,11 @@ template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false>
 hipError_t launchSeq(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
   auto kernel = traceSequential<SLOTS, WAVES, LDS_TABLES, REG>;
   const size_t lds = seqLdsBytes(WAVES, p.maxDepth, LDS_TABLES, p.ntri, p.nmat, p.nsph);
-  static size_t configured = 0; // per instantiation
-  if (lds > 48 * 1024 && lds > configured) {
+  if (lds > 48 * 1024) { // per launch: the attribute belongs to the current device's copy of the kernel
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds));
     if (e != hipSuccess) return e;
-    configured = lds;
   }
   hipLaunchKernelGGL(kernel, dim3(p.npass), dim3(WAVES == 1 ? 64 : 64 * (WAVES + 1)), lds, stream, p,
                      b.triGeom, b.triShade,
@@ -2203,13 +2201,11 @@ hipError_t launchSeqAuto(const TraceParams &p, const TraceBuffers &b, hipStream_
 
 hipError_t launchSeqSpec(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
   const size_t lds = specLdsBytes(p.ntri, p.nmat, p.nsph);
-  static size_t configured = 0;
-  if (lds > configured) {
+  {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(traceSequentialSpec),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds));
     if (e != hipSuccess) return e;
-    configured = lds;
   }
   hipLaunchKernelGGL(traceSequentialSpec, dim3(p.npass), dim3(64 * (kSpecWaves + 1)), lds, stream, p,
                      b.triGeom, b.spheres, b.triCompact, b.matTable, b.mtState, b.specState, b.stage,
@@ -2235,13 +2231,10 @@ hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hi
     // The speculative kernel spends a whole CU on a pass.  That pays while there are at most as many
     // passes as CUs; with more, one wave per pass on every SIMD is the better use of the chip.
     static const char *specEnv = std::getenv("PTW_SEQ_SPEC");
-    static int cus = 0;
-    if (cus == 0) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess ||
-          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-        cus = 256;
-    }
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
     const bool forced = specEnv && specEnv[0] == '2'; // PTW_SEQ_SPEC=2: whatever the pass count
     if (reg && !(specEnv && specEnv[0] == '0') && b.specState &&
         (forced || p.npass <= static_cast<uint32_t>(cus)))

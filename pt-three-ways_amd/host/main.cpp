@@ -4,7 +4,7 @@
 // Same flags, defaults and output as upstream:
 //   -w/--width -h/--height --max-cpus --spp --first-bounce-u --first-bounce-v --max-depth
 //   --seed --preview --save-every --way --scene --raw <output>
-// plus what a GPU way needs: --device N, --rng sequential|perpixel, --scenes-dir DIR.
+// plus what a GPU way needs: --device N, --gpus N, --rng sequential|perpixel, --scenes-dir DIR.
 // Everything goes through the C ABI of include/ptw.h - the same boundary a cgo/JNI/ctypes host
 // would bind - so this file is also the worked example for INTEGRATION.md.
 #include "../../include/ptw.h"
@@ -16,6 +16,7 @@
 #include <iostream>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -24,6 +25,7 @@ struct Options {
   ptw_render_params params;
   int maxCpus = 1;
   int saveEvery = 30;
+  int gpus = 1;
   bool raw = false;
   bool help = false;
   std::string way = "hip";
@@ -53,6 +55,7 @@ void printHelp() {
                "  --scene <scene>            cornell suzanne ce single-sphere multi-sphere example1 bbc-owl\n"
                "  --raw                      output in raw form\n"
                "  --device <n>               HIP device ordinal (0)\n"
+               "  --gpus <n>                 shard the passes over devices <device> .. <device>+n-1 (1)\n"
                "  --rng <policy>             sequential (reference-exact, default) | perpixel\n"
                "  --scenes-dir <dir>         where the .obj/.mtl files live (scenes)\n"
                "  -?, --help\n";
@@ -88,6 +91,7 @@ Options parse(int argc, const char *argv[]) {
     else if (a == "--scene") o.scene = value(i, a);
     else if (a == "--raw") o.raw = true;
     else if (a == "--device") o.params.device = toInt(a, value(i, a));
+    else if (a == "--gpus") o.gpus = toInt(a, value(i, a));
     else if (a == "--scenes-dir") o.scenesDir = value(i, a);
     else if (a == "--rng") {
       const std::string p = value(i, a);
@@ -186,7 +190,50 @@ int main(int argc, const char *argv[]) {
   const auto startTime = std::chrono::system_clock::now();
   int rc = PTW_OK;
   Progress progress;
-  if (o.saveEvery > 0 && o.params.samples_per_pixel > 1) {
+  if (o.gpus > 1) {
+    // One host thread per device, each with its own context (ptw_render creates one): device d
+    // renders a contiguous range of the passes - the reference's own decomposition, one task per
+    // pass merged with ArrayOutput::operator+= (src/dod/Scene.cpp:208-246) - into its own
+    // buffers; the partial frames are added in device order.
+    struct Shard {
+      std::vector<double> rgbSum;
+      std::vector<uint32_t> counts;
+      int rc = PTW_OK;
+      std::string error;
+    };
+    const int total = o.params.samples_per_pixel;
+    const bool shareDevice = std::getenv("PTW_CLI_SHARE_DEVICE") != nullptr; // tests on a 1-GPU box
+    std::vector<Shard> shards(static_cast<size_t>(o.gpus));
+    std::vector<std::thread> threads;
+    for (int g = 0; g < o.gpus; ++g) {
+      const int base = total / o.gpus, extra = total % o.gpus;
+      const int first = g * base + std::min(g, extra), count = base + (g < extra ? 1 : 0);
+      threads.emplace_back([&, g, first, count] {
+        Shard &sh = shards[static_cast<size_t>(g)];
+        sh.rgbSum.assign(out.rgbSum.size(), 0.0);
+        sh.counts.assign(out.counts.size(), 0u);
+        if (count == 0) return;
+        ptw_render_params part = o.params;
+        part.device = o.params.device + (shareDevice ? 0 : g);
+        part.first_pass = o.params.first_pass + first;
+        part.samples_per_pixel = count;
+        sh.rc = ptw_render(&view, &camera, &part, sh.rgbSum.data(), sh.counts.data(), nullptr, nullptr);
+        if (sh.rc != PTW_OK) sh.error = ptw_last_error(); // thread-local: copy it out here
+      });
+    }
+    for (auto &t : threads) t.join();
+    std::string firstError;
+    for (const Shard &sh : shards) {
+      if (sh.rc != PTW_OK && rc == PTW_OK) rc = sh.rc, firstError = sh.error;
+      for (size_t i = 0; i < out.rgbSum.size(); ++i) out.rgbSum[i] += sh.rgbSum[i];
+      for (size_t i = 0; i < out.counts.size(); ++i) out.counts[i] += sh.counts[i];
+    }
+    if (rc != PTW_OK) {
+      std::cerr << "render failed: " << firstError << "\n";
+      ptw_scene_destroy(scene);
+      return 1;
+    }
+  } else if (o.saveEvery > 0 && o.params.samples_per_pixel > 1) {
     // --save-every (main.cpp:331-343): render in pass chunks, re-saving the running sum when
     // the interval has elapsed.  Chunks continue the same pass sequence through first_pass.
     auto nextSave = startTime + std::chrono::seconds(o.saveEvery);

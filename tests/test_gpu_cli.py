@@ -74,6 +74,29 @@ def test_sequential_kernel_variants_write_identical_bytes(pkg, tmp_path, scene, 
     assert blobs["spec"] == blobs["reg"] == blobs["plain"] == blobs["spec_bands"]
 
 
+def test_gpus_flag_shards_passes_over_host_threads(pkg, tmp_path):
+    """--gpus N: one host thread and context per device, pass ranges merged in device order.  On a
+    1-GPU box the shards share the device (PTW_CLI_SHARE_DEVICE); the sum of the two partial frames
+    equals the single-device frame up to the order of the fp64 additions."""
+    from conftest import ROOT
+    args = ["-w", "24", "-h", "16", "--spp", "7", "--seed", "3", "--scene", "cornell", "--raw", "--save-every", "0"]
+    run_cli(pkg, args + [str(tmp_path / "one.raw")], ROOT)
+    run_cli(pkg, args + ["--gpus", "2", str(tmp_path / "two.raw")], ROOT, env={"PTW_CLI_SHARE_DEVICE": "1"})
+    run_cli(pkg, args + ["--gpus", "3", "--rng", "perpixel", str(tmp_path / "pp3.raw")], ROOT,
+            env={"PTW_CLI_SHARE_DEVICE": "1"})
+    a_rgb, a_cnt = pkg.raw_load(tmp_path / "one.raw")
+    b_rgb, b_cnt = pkg.raw_load(tmp_path / "two.raw")
+    assert np.array_equal(a_cnt, b_cnt) and np.all(b_cnt == 7)
+    assert np.max(np.abs(a_rgb - b_rgb)) <= 1e-12 * np.max(np.abs(a_rgb))
+    _, c_cnt = pkg.raw_load(tmp_path / "pp3.raw")
+    assert np.all(c_cnt == 7)
+    # without device sharing the second shard needs a second GPU: either it is there or the error says so
+    exe = str(pkg.LIB_PATH.parent / "pt_three_ways_hip")
+    proc = subprocess.run([exe] + args + ["--gpus", "2", str(tmp_path / "x.raw")], cwd=ROOT,
+                          capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0 or "device" in (proc.stdout + proc.stderr).lower()
+
+
 def test_cli_errors(pkg, tmp_path):
     from conftest import ROOT
     exe = str(pkg.LIB_PATH.parent / "pt_three_ways_hip")
