@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PTW_ABI_VERSION 1
+#define PTW_ABI_VERSION 2
 
 typedef enum ptw_status {
   PTW_OK = 0,
@@ -99,18 +99,34 @@ typedef struct ptw_render_params {
   int32_t seed;                  /* pass k uses mt19937(uint32(seed + first_pass + k))      */
   int32_t first_pass;            /* default 0: index of the first pass (multi-GPU / resume) */
   int32_t rng_policy;            /* ptw_rng_policy                                          */
-  /* Pixel window for PERPIXEL tile sharding: rows [row_begin, row_end) are rendered; the
-   * output buffers always describe the full width x height frame.  0,0 => all rows.        */
+  /* Pixel window for PERPIXEL tile sharding: of the rows [row_begin, row_end) those with
+   * (y % row_stride) == row_phase are rendered; the output buffers always describe the full
+   * width x height frame.  row_begin == row_end == 0 => all rows; row_begin == row_end != 0 =>
+   * an empty shard (nothing is rendered); row_stride 0 or 1 => every row of the window.
+   * Interleaved rows (stride = number of GPUs, phase = rank) balance the shards: what a pixel
+   * costs depends on what it sees.  A window or stride under PTW_RNG_SEQUENTIAL is
+   * PTW_ERR_UNSUPPORTED (pixels of a pass are serially dependent there: shard by first_pass). */
   int32_t row_begin;
   int32_t row_end;
   int32_t device;                /* HIP device ordinal for ptw_render()                     */
-  int32_t reserved[3];
+  int32_t row_stride;
+  int32_t row_phase;
+  int32_t reserved[1];
 } ptw_render_params;
 
 /* Progress callback, the analogue of `updateFunc(output)` (src/dod/Scene.cpp:245) and of
  * Progressifier (src/util/Progressifier.cpp:11-21): called on the calling thread between
  * device launches with the number of finished samples.  Return non-zero to cancel. */
 typedef int (*ptw_progress_fn)(void *user, uint64_t samples_done, uint64_t samples_total);
+/* The full form of `updateFunc(output)` (src/dod/Scene.cpp:245, used by src/main/main.cpp:331-343
+ * for --save-every): called on the calling thread between device launches with the caller's
+ * own rgb_sum / counts buffers brought up to date - every pixel finished so far holds all of its
+ * samples, the others hold what they held before the call (the hip way completes the frame
+ * band by band, top to bottom, with every pass of a band in one launch; the reference completes
+ * it pass by pass).  The buffers are a valid ArrayOutput at every call (sums + counts), so a
+ * snapshot can be saved, merged and resumed like the reference's.  Return non-zero to cancel. */
+typedef int (*ptw_update_fn)(void *user, uint64_t samples_done, uint64_t samples_total,
+                             const double *rgb_sum, const uint32_t *counts);
 
 const char *ptw_last_error(void);
 int ptw_abi_version(void);
@@ -167,6 +183,34 @@ int ptw_render(const ptw_scene_view *scene, const ptw_camera *camera,
                const ptw_render_params *params, double *rgb_sum, uint32_t *counts,
                ptw_progress_fn progress, void *user);
 
+/* The same call with everything the reference's driver does around it (src/main/main.cpp:
+ * 326-366): ONE context and one scene upload for the whole render, `update` handed the running
+ * framebuffer (see ptw_update_fn), and - with num_devices > 1 - the reference's decomposition
+ * over workers (one task per pass, src/dod/Scene.cpp:208-246) spread over the GPUs of the node:
+ *   PTW_RNG_SEQUENTIAL  device g renders a contiguous range of the passes (full frames),
+ *                       merged by ONE RCCL reduce(sum) of the fp64 sums + u32 counts
+ *                       (ArrayOutput::operator+=, src/util/ArrayOutput.cpp:48-56);
+ *   PTW_RNG_PERPIXEL    device g renders the image rows y with y % num_devices == g (all
+ *                       passes), assembled by ONE RCCL gather of the rows to the first device.
+ * One host thread per device; the collective runs over xGMI on the devices' own streams; the
+ * frame crosses PCIe once, from the first device.  Zero-initialise the struct for defaults. */
+typedef struct ptw_render_options {
+  int32_t num_devices;         /* 0 or 1: params->device only                                  */
+  int32_t min_updates;         /* with `update`: cut the frame into at least this many bands
+                                  (0 => 16); more bands = more frequent snapshots              */
+  const int32_t *devices;      /* [num_devices] HIP ordinals; NULL => device, device + 1, ...  */
+  ptw_progress_fn progress;    /* may be NULL                                                  */
+  void *progress_user;
+  ptw_update_fn update;        /* may be NULL; single-device renders only                      */
+  void *update_user;
+  int32_t share_device;        /* test hook for 1-GPU boxes: run the shards one after another
+                                  on params->device, accumulating on the device (no collective) */
+  int32_t reserved[3];
+} ptw_render_options;
+int ptw_render_ex(const ptw_scene_view *scene, const ptw_camera *camera,
+                  const ptw_render_params *params, double *rgb_sum, uint32_t *counts,
+                  const ptw_render_options *options);
+
 /* ---- Device-resident form of the same call (HBM in, HBM out) ---------------------------- */
 typedef struct ptw_context ptw_context;
 int ptw_context_create(int32_t device, ptw_context **out);
@@ -175,9 +219,13 @@ void ptw_context_destroy(ptw_context *ctx);
 int ptw_context_set_scene(ptw_context *ctx, const ptw_scene_view *scene);
 /* Enqueue the render on `hip_stream` (a hipStream_t, NULL = default stream).  d_rgb_sum and
  * d_counts are DEVICE pointers to width*height*3 doubles / width*height uint32 and are
- * accumulated into.  Asynchronous: the caller synchronises the stream.  If d_words is not
- * NULL it receives, per pass and pixel ([pass][y][x], uint32), the number of 32-bit RNG words
- * that sample consumed (parity instrumentation; SEQUENTIAL and PERPIXEL). */
+ * accumulated into.  Asynchronous: nothing here waits for the device; the caller synchronises
+ * the stream.  A context owns one set of scratch buffers (generator states, staging), so ONE
+ * render may be in flight per context: synchronise `hip_stream` before the next
+ * ptw_context_render / ptw_context_set_scene on the same context (renders on different
+ * contexts are independent).  If d_words is not NULL it receives, per pass and pixel
+ * ([pass][y][x], uint32), the number of 32-bit RNG words that sample consumed (parity
+ * instrumentation; SEQUENTIAL and PERPIXEL). */
 int ptw_context_render(ptw_context *ctx, const ptw_camera *camera,
                        const ptw_render_params *params, void *d_rgb_sum, void *d_counts,
                        void *d_words, void *hip_stream);
@@ -189,6 +237,8 @@ typedef struct ptw_kernel_stats {
   double resolve_ms;
   uint64_t samples;          /* samples traced by those launches                       */
   uint64_t rays;             /* intersect() calls made by those launches (0 if unknown) */
+  char trace_kernel[64];     /* the radiance kernel variant the library last launched,
+                                e.g. "traceSequentialSpec" (as the profiler names it)   */
 } ptw_kernel_stats;
 int ptw_context_enable_stats(ptw_context *ctx, int32_t enable);
 /* Synchronises the events it reads. */
@@ -205,6 +255,30 @@ int ptw_context_intersect(ptw_context *ctx, const double *rays, uint64_t n, doub
  * by the same device code the render kernels use. */
 int ptw_context_rng_doubles(ptw_context *ctx, int32_t rng_policy, uint32_t seed, uint32_t pixel,
                             uint32_t n, double *out);
+
+/* ---- Multi-GPU: the framebuffer collectives (RCCL over xGMI) ----------------------------
+ * One communicator per participating GPU.  Multi-process hosts (one process per GPU): rank 0
+ * calls ptw_comm_unique_id, ships the 128 bytes to the other ranks by whatever means it has
+ * (torch.distributed, MPI, a file), every rank calls ptw_comm_create.  Single-process hosts:
+ * ptw_comm_create_all.  The collectives are enqueued on `hip_stream` and are asynchronous. */
+#define PTW_COMM_ID_BYTES 128
+typedef struct ptw_comm ptw_comm;
+int ptw_comm_unique_id(uint8_t id_out[PTW_COMM_ID_BYTES]);
+int ptw_comm_create(const uint8_t id[PTW_COMM_ID_BYTES], int32_t world_size, int32_t rank,
+                    int32_t device, ptw_comm **out);
+int ptw_comm_create_all(int32_t num_devices, const int32_t *devices, ptw_comm **out_comms);
+void ptw_comm_destroy(ptw_comm *comm);
+/* `output += pass` for whole framebuffers (ArrayOutput::operator+=, ArrayOutput.cpp:48-56):
+ * the fp64 sums (npix * 3) and the u32 counts (npix) of every rank are summed into rank `root`'s
+ * buffers (ncclReduce; the other ranks' buffers are left as they are).  In place. */
+int ptw_comm_reduce_framebuffer(ptw_comm *comm, void *d_rgb_sum, void *d_counts, uint64_t npix,
+                                int32_t root, void *hip_stream);
+/* Assembles a frame rendered with interleaved rows (row_stride = world_size, row_phase = rank):
+ * every rank sends the rows it owns, rank `root` receives them into the same rows of its own
+ * buffers (rows of other ranks are overwritten there, its own are kept).  A gather of 1/world of
+ * the frame per rank - point-to-point over the xGMI links into `root`. */
+int ptw_comm_gather_rows(ptw_comm *comm, void *d_rgb_sum, void *d_counts, int32_t width,
+                         int32_t height, int32_t root, void *hip_stream);
 
 /* ---- ArrayOutput surface, src/util/ArrayOutput.cpp ------------------------------------- */
 /* .raw: header {u32 signature=1, version=1, height, width} then per pixel 3 x f64 sum +

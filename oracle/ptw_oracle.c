@@ -541,14 +541,22 @@ static int render_pass_impl(const ptw_scene_view *scene, const ptw_camera *camer
   rng_t rng;
   memset(&rng, 0, sizeof rng);
   rng.policy = rp->rng_policy;
-  int row_begin = 0, row_end = height;
+  int row_begin = 0, row_end = height, row_stride = 1, row_phase = 0;
   if (rp->rng_policy == PTW_RNG_SEQUENTIAL) {
     oracle_mt_seed(&rng.mt, pass_seed);
-  } else if (rp->row_end > rp->row_begin) {
-    row_begin = rp->row_begin;
-    row_end = rp->row_end;
+  } else {
+    /* the row window of include/ptw.h: (0,0) = all rows, begin == end != 0 = empty shard */
+    if (rp->row_begin != 0 || rp->row_end != 0) {
+      row_begin = rp->row_begin;
+      row_end = rp->row_end;
+    }
+    if (rp->row_stride > 1) {
+      row_stride = rp->row_stride;
+      row_phase = rp->row_phase;
+    }
   }
   for (int y = row_begin; y < row_end; ++y) {
+    if (y % row_stride != row_phase) continue;
     for (int x = 0; x < width; ++x) {
       const size_t pix = (size_t)x + (size_t)y * width;
       if (rp->rng_policy == PTW_RNG_PERPIXEL) sfc32_seed(&rng.sfc, pass_seed, (uint32_t)pix);
@@ -629,21 +637,29 @@ int oracle_render(const ptw_scene_view *scene, const ptw_camera *camera,
   free(tids);
   pthread_mutex_destroy(&job.lock);
 
-  int row_begin = 0, row_end = params->height;
-  if (params->rng_policy == PTW_RNG_PERPIXEL && params->row_end > params->row_begin) {
-    row_begin = params->row_begin;
-    row_end = params->row_end;
+  int row_begin = 0, row_end = params->height, row_stride = 1, row_phase = 0;
+  if (params->rng_policy == PTW_RNG_PERPIXEL) {
+    if (params->row_begin != 0 || params->row_end != 0) {
+      row_begin = params->row_begin;
+      row_end = params->row_end;
+    }
+    if (params->row_stride > 1) {
+      row_stride = params->row_stride;
+      row_phase = params->row_phase;
+    }
   }
   /* output += pass (ArrayOutput::operator+=, ArrayOutput.cpp:48-56), in pass order */
   for (int pass = 0; pass < spp; ++pass) {
     double *buf = job.pass_buffers[pass];
     if (!buf) continue;
-    for (size_t pix = (size_t)row_begin * params->width; pix < (size_t)row_end * params->width;
-         ++pix) {
-      rgb_sum[pix * 3 + 0] += buf[pix * 3 + 0];
-      rgb_sum[pix * 3 + 1] += buf[pix * 3 + 1];
-      rgb_sum[pix * 3 + 2] += buf[pix * 3 + 2];
-      counts[pix] += 1;
+    for (int y = row_begin; y < row_end; ++y) {
+      if (y % row_stride != row_phase) continue;
+      for (size_t pix = (size_t)y * params->width; pix < (size_t)(y + 1) * params->width; ++pix) {
+        rgb_sum[pix * 3 + 0] += buf[pix * 3 + 0];
+        rgb_sum[pix * 3 + 1] += buf[pix * 3 + 1];
+        rgb_sum[pix * 3 + 2] += buf[pix * 3 + 2];
+        counts[pix] += 1;
+      }
     }
     free(buf);
   }

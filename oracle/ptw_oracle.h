@@ -52,7 +52,7 @@ void oracle_camera_ray(const ptw_camera *cam, int32_t px, int32_t py, uint32_t s
 /* ---- One pass of Scene::render's worker lambda (src/dod/Scene.cpp:209-219) -------------
  * radiance_out: width*height*3 doubles (this pass's per-pixel radiance, NOT accumulated);
  * words_out (may be NULL): width*height uint32, RNG words consumed per pixel.
- * Honours params->rng_policy, row_begin/row_end (PERPIXEL only), first_pass. */
+ * Honours params->rng_policy, the row window and row_stride/row_phase (PERPIXEL only), first_pass. */
 int oracle_render_pass(const ptw_scene_view *scene, const ptw_camera *camera,
                        const ptw_render_params *params, int32_t pass_index,
                        double *radiance_out, uint32_t *words_out);

@@ -97,16 +97,26 @@ class RenderParams(C.Structure):
                 ("first_bounce_u", C.c_int32), ("first_bounce_v", C.c_int32),
                 ("seed", C.c_int32), ("first_pass", C.c_int32), ("rng_policy", C.c_int32),
                 ("row_begin", C.c_int32), ("row_end", C.c_int32), ("device", C.c_int32),
-                ("reserved", C.c_int32 * 3)]
+                ("row_stride", C.c_int32), ("row_phase", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class KernelStats(C.Structure):
     _fields_ = [("trace_launches", C.c_uint64), ("trace_ms", C.c_double),
                 ("resolve_launches", C.c_uint64), ("resolve_ms", C.c_double),
-                ("samples", C.c_uint64), ("rays", C.c_uint64)]
+                ("samples", C.c_uint64), ("rays", C.c_uint64), ("trace_kernel", C.c_char * 64)]
 
 
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64)
+UPDATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p)
+COMM_ID_BYTES = 128
+
+
+class RenderOptions(C.Structure):
+    """ptw_render_options (include/ptw.h): multi-device sharding and callbacks of ptw_render_ex."""
+    _fields_ = [("num_devices", C.c_int32), ("min_updates", C.c_int32),
+                ("devices", C.POINTER(C.c_int32)), ("progress", PROGRESS_FN),
+                ("progress_user", C.c_void_p), ("update", UPDATE_FN), ("update_user", C.c_void_p),
+                ("share_device", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 _D3 = C.POINTER(C.c_double)
 
@@ -143,6 +153,16 @@ _sig("ptw_camera_look_at", C.c_int, _D3, _D3, _D3, C.c_int32, C.c_int32, C.c_dou
 _sig("ptw_camera_set_focus", C.c_int, C.POINTER(Camera), _D3, C.c_double)
 _sig("ptw_render", C.c_int, C.POINTER(SceneView), C.POINTER(Camera), C.POINTER(RenderParams),
      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("ptw_render_ex", C.c_int, C.POINTER(SceneView), C.POINTER(Camera), C.POINTER(RenderParams),
+     C.c_void_p, C.c_void_p, C.POINTER(RenderOptions))
+_sig("ptw_comm_unique_id", C.c_int, C.c_void_p)
+_sig("ptw_comm_create", C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p))
+_sig("ptw_comm_create_all", C.c_int, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p))
+_sig("ptw_comm_destroy", None, C.c_void_p)
+_sig("ptw_comm_reduce_framebuffer", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+     C.c_int32, C.c_void_p)
+_sig("ptw_comm_gather_rows", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+     C.c_int32, C.c_void_p)
 _sig("ptw_context_create", C.c_int, C.c_int32, C.POINTER(C.c_void_p))
 _sig("ptw_context_destroy", None, C.c_void_p)
 _sig("ptw_context_set_scene", C.c_int, C.c_void_p, C.POINTER(SceneView))
@@ -277,8 +297,12 @@ class Scene:
 
 
 def render(scene: Scene, camera: Camera, params: RenderParams, rgb_sum=None, counts=None,
-           progress=None):
-    """dod::Scene::render through ptw_render (host buffers in, host buffers out)."""
+           progress=None, update=None, num_devices=0, share_device=False, min_updates=0):
+    """dod::Scene::render through ptw_render / ptw_render_ex (host buffers in and out).
+
+    `progress(done, total)` and `update(done, total, rgb_sum, counts)` mirror the reference's
+    Progressifier and `updateFunc(output)`; a true return value cancels.  `num_devices` > 1
+    spreads the render over the GPUs of the node (one RCCL collective at the end)."""
     n = params.width * params.height
     if rgb_sum is None:
         rgb_sum = np.zeros((params.height, params.width, 3), dtype=np.float64)
@@ -288,10 +312,60 @@ def render(scene: Scene, camera: Camera, params: RenderParams, rgb_sum=None, cou
     assert counts.dtype == np.uint32 and counts.size == n and counts.flags.c_contiguous
     cb = PROGRESS_FN(lambda user, done, total: int(bool(progress(done, total)))) if progress else None
     view = scene.view()
-    _check(lib.ptw_render(C.byref(view), C.byref(camera), C.byref(params),
-                          rgb_sum.ctypes.data, counts.ctypes.data,
-                          C.cast(cb, C.c_void_p) if cb else None, None))
+    if update is None and num_devices <= 1:
+        _check(lib.ptw_render(C.byref(view), C.byref(camera), C.byref(params),
+                              rgb_sum.ctypes.data, counts.ctypes.data,
+                              C.cast(cb, C.c_void_p) if cb else None, None))
+        return rgb_sum, counts
+    opt = RenderOptions()
+    opt.num_devices = int(num_devices)
+    opt.share_device = int(bool(share_device))
+    opt.min_updates = int(min_updates)
+    if cb:
+        opt.progress = cb
+    ucb = None
+    if update:
+        # the pointers handed to the callback are the caller's own buffers
+        ucb = UPDATE_FN(lambda user, done, total, r, c: int(bool(update(done, total, rgb_sum, counts))))
+        opt.update = ucb
+    _check(lib.ptw_render_ex(C.byref(view), C.byref(camera), C.byref(params),
+                             rgb_sum.ctypes.data, counts.ctypes.data, C.byref(opt)))
     return rgb_sum, counts
+
+
+class Comm:
+    """One rank's framebuffer communicator (ptw_comm_*: RCCL behind the C ABI)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        _check(lib.ptw_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def create(cls, uid: bytes, world_size: int, rank: int, device: int) -> "Comm":
+        assert len(uid) == COMM_ID_BYTES
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(uid)
+        h = C.c_void_p()
+        _check(lib.ptw_comm_create(buf, world_size, rank, device, C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if self._h:
+            lib.ptw_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def reduce_framebuffer(self, d_rgb_sum: int, d_counts: int, npix: int, root: int = 0, stream: int = 0):
+        _check(lib.ptw_comm_reduce_framebuffer(self._h, C.c_void_p(d_rgb_sum), C.c_void_p(d_counts),
+                                               npix, root, C.c_void_p(stream) if stream else None))
+
+    def gather_rows(self, d_rgb_sum: int, d_counts: int, width: int, height: int, root: int = 0,
+                    stream: int = 0):
+        _check(lib.ptw_comm_gather_rows(self._h, C.c_void_p(d_rgb_sum), C.c_void_p(d_counts), width,
+                                        height, root, C.c_void_p(stream) if stream else None))
 
 
 class Context:

@@ -8,9 +8,12 @@
 #include "../host/precompute.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -74,7 +77,11 @@ struct ptw_context {
   DeviceArray<unsigned long long> sampleQueue; // work counter of the persistent kernel
   DeviceArray<unsigned long long> rays; // per-pass intersect() counters, accumulated
   uint64_t rayCarry = 0;                // counts folded in when `rays` had to grow
-  std::vector<uint32_t> hostSeedStates; // kept alive for the async upload
+  // Host sources of the asynchronous uploads of a render; they live in the context because
+  // the upload may still be in flight when ptw_context_render returns (one render in flight per
+  // context, see include/ptw.h).
+  std::vector<uint32_t> hostSeedStates, hostPos;
+  const char *traceKernel = ""; // variant name of the last trace launch
 
   bool statsEnabled = false;
   struct Timed {
@@ -84,17 +91,21 @@ struct ptw_context {
   std::vector<Timed> timed;
   uint64_t statSamples = 0;
 
-  size_t stageBudgetBytes = size_t(256) << 20; // per-band staging buffer budget
+  // Per-band staging buffer budget: npass x bandPix x 24 B.  4 GiB keeps the headline frame
+  // (1024 x 1024 @ 256 spp = 6.4 GB staged) to two launches; the part has 288 GB.
+  size_t stageBudgetBytes = size_t(4) << 30;
 
   void activate() const { check(hipSetDevice(device), "hipSetDevice"); }
   // Reads back and zeroes the per-pass ray counters (synchronous).
   uint64_t drainRays() {
     if (!rays.capacity) return 0;
+    check(hipDeviceSynchronize(), "hipDeviceSynchronize"); // counters of renders on any stream
     std::vector<unsigned long long> host(rays.capacity);
     check(hipMemcpy(host.data(), rays.ptr, host.size() * sizeof(unsigned long long),
                     hipMemcpyDeviceToHost),
           "D2H rays");
     check(hipMemset(rays.ptr, 0, host.size() * sizeof(unsigned long long)), "memset");
+    check(hipDeviceSynchronize(), "hipDeviceSynchronize");
     uint64_t total = 0;
     for (auto v : host) total += v;
     return total;
@@ -125,12 +136,39 @@ void validate(const ptw_render_params &p) {
   if (p.samples_per_pixel < 0) throw std::invalid_argument("samples_per_pixel must be >= 0");
   if (p.max_depth > kMaxDepth)
     throw DeviceError(PTW_ERR_UNSUPPORTED, "max_depth above " + std::to_string(kMaxDepth));
-  if (p.first_bounce_u < 0 || p.first_bounce_v < 0)
-    throw std::invalid_argument("first_bounce_u/v must be >= 0");
+  // A zero fan-out makes the reference divide 0 by 0 (Scene.cpp:178); it is not a render.
+  if (p.first_bounce_u < 1 || p.first_bounce_v < 1)
+    throw std::invalid_argument("first_bounce_u/v must be >= 1");
+  if (static_cast<int64_t>(p.first_bounce_u) * p.first_bounce_v > (1 << 20))
+    throw std::invalid_argument("first_bounce_u * first_bounce_v too large");
   if (p.rng_policy != PTW_RNG_SEQUENTIAL && p.rng_policy != PTW_RNG_PERPIXEL)
     throw std::invalid_argument("unknown rng_policy");
   if (p.row_end < p.row_begin || p.row_begin < 0 || p.row_end > p.height)
     throw std::invalid_argument("bad row window");
+  if (p.row_stride < 0 || p.row_phase < 0 || (p.row_stride > 1 && p.row_phase >= p.row_stride) ||
+      (p.row_stride <= 1 && p.row_phase != 0))
+    throw std::invalid_argument("bad row_stride / row_phase");
+  if (p.rng_policy == PTW_RNG_SEQUENTIAL && (p.row_begin != 0 || p.row_end != 0 || p.row_stride > 1))
+    throw DeviceError(PTW_ERR_UNSUPPORTED,
+                      "a row window needs PTW_RNG_PERPIXEL: under PTW_RNG_SEQUENTIAL the pixels of a "
+                      "pass share one stream (shard by first_pass instead)");
+}
+
+// The image rows a render covers: first row, row stride, number of rows.
+struct RowSet {
+  int first, stride, count;
+};
+RowSet rowsOf(const ptw_render_params &p) {
+  const bool all = p.row_begin == 0 && p.row_end == 0;
+  const int begin = all ? 0 : p.row_begin, end = all ? p.height : p.row_end;
+  const int stride = p.row_stride > 1 ? p.row_stride : 1;
+  // first row >= begin that is congruent to row_phase
+  int first = begin + ((p.row_phase - begin % stride) + stride) % stride;
+  RowSet r;
+  r.first = first;
+  r.stride = stride;
+  r.count = first < end ? (end - first + stride - 1) / stride : 0;
+  return r;
 }
 
 TraceParams makeTraceParams(const ptw_context &ctx, const ptw_camera &cam,
@@ -159,15 +197,18 @@ TraceParams makeTraceParams(const ptw_context &ctx, const ptw_camera &cam,
   t.passSeedBase = static_cast<uint32_t>(p.seed + p.first_pass);
   t.npix = static_cast<uint32_t>(p.width) * static_cast<uint32_t>(p.height);
   t.npass = static_cast<uint32_t>(p.samples_per_pixel);
+  t.rowFirst = 0;
+  t.rowStride = 1;
   return t;
 }
 
 // Enqueues the whole render on `stream`.  `betweenBands`, when set, is called after each
-// band's launches have been enqueued with the samples enqueued so far; returning true cancels.
+// band's launches have been enqueued with the band's local pixel range and the samples enqueued so
+// far; returning true cancels.  `minBands` > 1 cuts the frame into at least that many bands.
 template <typename BetweenBands>
 void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_params &p,
                    double *dRgb, uint32_t *dCounts, uint32_t *dWords, hipStream_t stream,
-                   BetweenBands &&betweenBands) {
+                   int minBands, BetweenBands &&betweenBands) {
   validate(p);
   if (!ctx.haveScene) throw std::invalid_argument("no scene set on this context");
   ctx.activate();
@@ -176,22 +217,26 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   TraceParams t = makeTraceParams(ctx, cam, p);
   const bool sequential = p.rng_policy == PTW_RNG_SEQUENTIAL;
 
-  uint32_t pixFirst = 0, pixLast = t.npix;
-  if (!sequential && p.row_end > p.row_begin) {
-    pixFirst = static_cast<uint32_t>(p.row_begin) * p.width;
-    pixLast = static_cast<uint32_t>(p.row_end) * p.width;
-  }
-  const uint32_t pixTotal = pixLast - pixFirst;
+  const RowSet rows = rowsOf(p);
+  if (rows.count == 0) return; // an empty shard contributes nothing
+  t.rowFirst = rows.first;
+  t.rowStride = rows.stride;
+  const uint32_t pixTotal = static_cast<uint32_t>(rows.count) * static_cast<uint32_t>(p.width);
 
   // Band size: the staging buffer holds npass x bandPix x 3 doubles.
   uint64_t bandPix = ctx.stageBudgetBytes / (static_cast<uint64_t>(npass) * 24);
+  if (minBands > 1) bandPix = std::min<uint64_t>(bandPix, (pixTotal + minBands - 1) / minBands);
   bandPix = std::max<uint64_t>(bandPix, 64);
   bandPix = std::min<uint64_t>(bandPix, pixTotal);
+  // equal bands (the last one is not a sliver)
+  const uint64_t nBands = (pixTotal + bandPix - 1) / bandPix;
+  bandPix = (pixTotal + nBands - 1) / nBands;
   ctx.stage.reserve(static_cast<size_t>(npass) * bandPix * 3);
   if (npass > ctx.rays.capacity) {
     ctx.rayCarry += ctx.drainRays();
     ctx.rays.reserve(npass);
     check(hipMemset(ctx.rays.ptr, 0, npass * sizeof(unsigned long long)), "memset");
+    check(hipDeviceSynchronize(), "hipDeviceSynchronize");
   }
 
   if (sequential) {
@@ -200,12 +245,8 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
     for (uint32_t k = 0; k < npass; ++k)
       seedMt19937(t.passSeedBase + k, &ctx.hostSeedStates[static_cast<size_t>(k) * kMtWords]);
     ctx.mtState.upload(ctx.hostSeedStates.data(), ctx.hostSeedStates.size(), stream);
-    std::vector<uint32_t> pos(npass, kMtDoubles); // 312 = "regenerate before the first draw"
-    ctx.mtPos.reserve(npass);
-    check(hipMemcpyAsync(ctx.mtPos.ptr, pos.data(), npass * sizeof(uint32_t),
-                         hipMemcpyHostToDevice, stream),
-          "H2D mtPos");
-    check(hipStreamSynchronize(stream), "sync after seeding"); // `pos` is a local
+    ctx.hostPos.assign(npass, kMtDoubles); // 312 = "regenerate before the first draw"
+    ctx.mtPos.upload(ctx.hostPos.data(), npass, stream);
     ctx.specState.reserve(static_cast<size_t>(npass) * kSpecStateDoubles);
   }
 
@@ -241,20 +282,18 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   };
 
   uint64_t done = 0;
-  for (uint32_t begin = pixFirst; begin < pixLast; begin += static_cast<uint32_t>(bandPix)) {
+  for (uint32_t begin = 0; begin < pixTotal; begin += static_cast<uint32_t>(bandPix)) {
     t.pixBegin = begin;
-    t.pixCount = static_cast<uint32_t>(std::min<uint64_t>(bandPix, pixLast - begin));
-    t.firstBand = begin == pixFirst;
+    t.pixCount = static_cast<uint32_t>(std::min<uint64_t>(bandPix, pixTotal - begin));
+    t.firstBand = begin == 0;
     if (sequential)
-      timedLaunch(true, [&] { return launchTraceSequential(t, b, stream); });
+      timedLaunch(true, [&] { return launchTraceSequential(t, b, stream, &ctx.traceKernel); });
     else
-      timedLaunch(true, [&] { return launchTracePerPixel(t, b, stream); });
-    timedLaunch(false, [&] {
-      return launchResolve(ctx.stage.ptr, npass, t.pixBegin, t.pixCount, dRgb, dCounts, stream);
-    });
+      timedLaunch(true, [&] { return launchTracePerPixel(t, b, stream, &ctx.traceKernel); });
+    timedLaunch(false, [&] { return launchResolve(t, ctx.stage.ptr, dRgb, dCounts, stream); });
     done += static_cast<uint64_t>(t.pixCount) * npass;
     ctx.statSamples += static_cast<uint64_t>(t.pixCount) * npass;
-    if (betweenBands(done, static_cast<uint64_t>(pixTotal) * npass)) break;
+    if (betweenBands(t, done, static_cast<uint64_t>(pixTotal) * npass)) break;
   }
 }
 
@@ -325,7 +364,8 @@ int ptw_context_render(ptw_context *ctx, const ptw_camera *camera, const ptw_ren
   PTW_GUARD_BEGIN
   enqueueRender(*ctx, *camera, *params, static_cast<double *>(d_rgb_sum),
                 static_cast<uint32_t *>(d_counts), static_cast<uint32_t *>(d_words),
-                static_cast<hipStream_t>(hip_stream), [](uint64_t, uint64_t) { return false; });
+                static_cast<hipStream_t>(hip_stream), 0,
+                [](const TraceParams &, uint64_t, uint64_t) { return false; });
   return PTW_OK;
   PTW_GUARD_END
 }
@@ -356,6 +396,7 @@ int ptw_context_get_stats(ptw_context *ctx, ptw_kernel_stats *out, int32_t reset
   out->samples = ctx->statSamples;
   ctx->rayCarry += ctx->drainRays();
   out->rays = ctx->rayCarry;
+  std::snprintf(out->trace_kernel, sizeof out->trace_kernel, "%s", ctx->traceKernel);
   if (reset) {
     ctx->clearEvents();
     ctx->statSamples = 0;
@@ -422,37 +463,226 @@ int ptw_context_rng_doubles(ptw_context *ctx, int32_t rng_policy, uint32_t seed,
 int ptw_render(const ptw_scene_view *scene, const ptw_camera *camera,
                const ptw_render_params *params, double *rgb_sum, uint32_t *counts,
                ptw_progress_fn progress, void *user) {
-  if (!scene || !camera || !params || !rgb_sum || !counts) return invalid("null pointer");
-  ptw_context *raw = nullptr;
-  int rc = ptw_context_create(params->device, &raw);
-  if (rc != PTW_OK) return rc;
-  std::unique_ptr<ptw_context, void (*)(ptw_context *)> ctx(raw, ptw_context_destroy);
-  rc = ptw_context_set_scene(ctx.get(), scene);
-  if (rc != PTW_OK) return rc;
-  PTW_GUARD_BEGIN
-  validate(*params);
-  const size_t npix = static_cast<size_t>(params->width) * params->height;
-  DeviceArray<double> dRgb;
-  DeviceArray<uint32_t> dCounts;
-  dRgb.upload(rgb_sum, npix * 3, nullptr);
-  dCounts.upload(counts, npix, nullptr);
-  bool cancelled = false;
-  enqueueRender(*ctx, *camera, *params, dRgb.ptr, dCounts.ptr, nullptr, nullptr,
-                [&](uint64_t done, uint64_t total) {
-                  if (!progress) return false;
-                  check(hipStreamSynchronize(nullptr), "band");
-                  cancelled = progress(user, done, total) != 0;
-                  return cancelled;
-                });
-  check(hipStreamSynchronize(nullptr), "render");
-  check(hipMemcpy(rgb_sum, dRgb.ptr, npix * 3 * sizeof(double), hipMemcpyDeviceToHost), "D2H");
-  check(hipMemcpy(counts, dCounts.ptr, npix * sizeof(uint32_t), hipMemcpyDeviceToHost), "D2H");
-  if (cancelled) {
-    setLastError("cancelled by the progress callback");
-    return PTW_ERR_INVALID;
-  }
-  return PTW_OK;
-  PTW_GUARD_END
+  ptw_render_options opt;
+  std::memset(&opt, 0, sizeof opt);
+  opt.progress = progress;
+  opt.progress_user = user;
+  return ptw_render_ex(scene, camera, params, rgb_sum, counts, &opt);
 }
 
 } // extern "C"
+
+namespace {
+
+// One device's share of a ptw_render_ex call: its own context (one scene upload), its own
+// stream, device-resident framebuffer.
+struct DeviceShard {
+  int device = 0;
+  ptw_render_params params;
+  std::unique_ptr<ptw_context, void (*)(ptw_context *)> ctx{nullptr, ptw_context_destroy};
+  DeviceArray<double> rgb;
+  DeviceArray<uint32_t> counts;
+  hipStream_t stream = nullptr;
+  int status = PTW_OK;
+  std::string error;
+  ~DeviceShard() {
+    if (stream) {
+      (void)hipSetDevice(device);
+      (void)hipStreamDestroy(stream);
+    }
+  }
+};
+
+// Runs `body` and records a failure in the shard instead of letting it escape the thread.
+template <typename F>
+void guarded(DeviceShard &sh, F &&body) {
+  try {
+    body();
+  } catch (...) {
+    sh.status = translateException();
+    sh.error = ptw_last_error(); // thread-local: copy it out on the thread that failed
+  }
+}
+
+void renderSingle(const ptw_scene_view &scene, const ptw_camera &camera,
+                  const ptw_render_params &params, double *rgbSum, uint32_t *counts,
+                  const ptw_render_options &opt) {
+  ptw_context *raw = nullptr;
+  if (ptw_context_create(params.device, &raw) != PTW_OK) throw DeviceError(PTW_ERR_NO_DEVICE, ptw_last_error());
+  std::unique_ptr<ptw_context, void (*)(ptw_context *)> ctx(raw, ptw_context_destroy);
+  if (int rc = ptw_context_set_scene(ctx.get(), &scene); rc != PTW_OK) throw DeviceError(rc, ptw_last_error());
+  const size_t npix = static_cast<size_t>(params.width) * params.height;
+  DeviceArray<double> dRgb;
+  DeviceArray<uint32_t> dCounts;
+  dRgb.upload(rgbSum, npix * 3, nullptr);
+  dCounts.upload(counts, npix, nullptr);
+  bool cancelled = false;
+  const bool talk = opt.progress || opt.update;
+  // With a callback the frame is cut into bands so that there is something to report: 20 for
+  // the 5 % steps of the reference's Progressifier, `min_updates` for snapshots.
+  const int minBands = opt.update ? (opt.min_updates > 0 ? opt.min_updates : 16) : (opt.progress ? 20 : 0);
+  enqueueRender(*ctx, camera, params, dRgb.ptr, dCounts.ptr, nullptr, nullptr, minBands,
+                [&](const TraceParams &t, uint64_t done, uint64_t total) {
+                  if (!talk) return false;
+                  check(hipStreamSynchronize(nullptr), "band");
+                  if (opt.update) {
+                    // bring the caller's buffers up to date: the image rows this band touched
+                    const size_t w = static_cast<size_t>(params.width);
+                    const size_t r0 = t.pixBegin / w, r1 = (t.pixBegin + t.pixCount - 1) / w;
+                    auto copyRows = [&](size_t row, size_t rows) {
+                      check(hipMemcpy(rgbSum + row * w * 3, dRgb.ptr + row * w * 3,
+                                      rows * w * 3 * sizeof(double), hipMemcpyDeviceToHost), "D2H");
+                      check(hipMemcpy(counts + row * w, dCounts.ptr + row * w,
+                                      rows * w * sizeof(uint32_t), hipMemcpyDeviceToHost), "D2H");
+                    };
+                    if (t.rowStride == 1) {
+                      copyRows(static_cast<size_t>(t.rowFirst) + r0, r1 - r0 + 1);
+                    } else { // interleaved rows are not contiguous in the frame
+                      for (size_t r = r0; r <= r1; ++r)
+                        copyRows(static_cast<size_t>(t.rowFirst) + r * static_cast<size_t>(t.rowStride), 1);
+                    }
+                    if (opt.update(opt.update_user, done, total, rgbSum, counts) != 0) cancelled = true;
+                  }
+                  if (opt.progress && opt.progress(opt.progress_user, done, total) != 0) cancelled = true;
+                  return cancelled;
+                });
+  check(hipStreamSynchronize(nullptr), "render");
+  check(hipMemcpy(rgbSum, dRgb.ptr, npix * 3 * sizeof(double), hipMemcpyDeviceToHost), "D2H");
+  check(hipMemcpy(counts, dCounts.ptr, npix * sizeof(uint32_t), hipMemcpyDeviceToHost), "D2H");
+  if (cancelled) throw std::invalid_argument("cancelled by the callback");
+}
+
+void renderMulti(const ptw_scene_view &scene, const ptw_camera &camera,
+                 const ptw_render_params &params, double *rgbSum, uint32_t *counts,
+                 const ptw_render_options &opt) {
+  if (opt.update)
+    throw DeviceError(PTW_ERR_UNSUPPORTED, "update callbacks need a single-device render");
+  validate(params);
+  const int n = opt.num_devices;
+  const bool sequential = params.rng_policy == PTW_RNG_SEQUENTIAL;
+  if (!sequential && (params.row_begin != 0 || params.row_end != 0 || params.row_stride > 1))
+    throw DeviceError(PTW_ERR_UNSUPPORTED, "multi-device renders shard the rows themselves");
+  const size_t npix = static_cast<size_t>(params.width) * params.height;
+  const int total = params.samples_per_pixel;
+
+  std::vector<DeviceShard> shards(static_cast<size_t>(n));
+  std::vector<int32_t> devices(static_cast<size_t>(n));
+  for (int g = 0; g < n; ++g) {
+    devices[g] = opt.share_device ? params.device : (opt.devices ? opt.devices[g] : params.device + g);
+    DeviceShard &sh = shards[g];
+    sh.device = devices[g];
+    sh.params = params;
+    sh.params.device = devices[g];
+    if (sequential) { // the reference's decomposition: ranges of passes (Scene.cpp:208-246)
+      const int base = total / n, extra = total % n;
+      sh.params.first_pass = params.first_pass + g * base + std::min(g, extra);
+      sh.params.samples_per_pixel = base + (g < extra ? 1 : 0);
+    } else {          // interleaved image rows
+      sh.params.row_stride = n;
+      sh.params.row_phase = g;
+    }
+  }
+
+  if (opt.share_device) {
+    // Test hook for 1-GPU boxes: the same shards, one after another, accumulated on the device.
+    DeviceShard &sh = shards[0];
+    ptw_context *raw = nullptr;
+    if (ptw_context_create(sh.device, &raw) != PTW_OK) throw DeviceError(PTW_ERR_NO_DEVICE, ptw_last_error());
+    sh.ctx.reset(raw);
+    if (int rc = ptw_context_set_scene(sh.ctx.get(), &scene); rc != PTW_OK) throw DeviceError(rc, ptw_last_error());
+    sh.rgb.upload(rgbSum, npix * 3, nullptr);
+    sh.counts.upload(counts, npix, nullptr);
+    for (int g = 0; g < n; ++g) {
+      enqueueRender(*sh.ctx, camera, shards[g].params, sh.rgb.ptr, sh.counts.ptr, nullptr, nullptr, 0,
+                    [](const TraceParams &, uint64_t, uint64_t) { return false; });
+      check(hipStreamSynchronize(nullptr), "render");
+      if (opt.progress) opt.progress(opt.progress_user, static_cast<uint64_t>(g + 1), static_cast<uint64_t>(n));
+    }
+    check(hipMemcpy(rgbSum, sh.rgb.ptr, npix * 3 * sizeof(double), hipMemcpyDeviceToHost), "D2H");
+    check(hipMemcpy(counts, sh.counts.ptr, npix * sizeof(uint32_t), hipMemcpyDeviceToHost), "D2H");
+    return;
+  }
+
+  std::vector<ptw_comm *> comms(static_cast<size_t>(n), nullptr);
+  if (ptw_comm_create_all(n, devices.data(), comms.data()) != PTW_OK)
+    throw DeviceError(PTW_ERR_HIP, ptw_last_error());
+  struct CommGuard {
+    std::vector<ptw_comm *> &c;
+    ~CommGuard() {
+      for (auto *x : c) ptw_comm_destroy(x);
+    }
+  } commGuard{comms};
+
+  // One host thread per device: context + scene upload, render, then the one collective.  A
+  // rank that failed still enters the collective (with whatever its buffers hold) so that the
+  // others are not left waiting; the error is reported afterwards.
+  std::vector<std::thread> threads;
+  for (int g = 0; g < n; ++g)
+    threads.emplace_back([&, g] {
+      DeviceShard &sh = shards[g];
+      guarded(sh, [&] {
+        ptw_context *raw = nullptr;
+        if (ptw_context_create(sh.device, &raw) != PTW_OK) throw DeviceError(PTW_ERR_NO_DEVICE, ptw_last_error());
+        sh.ctx.reset(raw);
+        if (int rc = ptw_context_set_scene(sh.ctx.get(), &scene); rc != PTW_OK) throw DeviceError(rc, ptw_last_error());
+        check(hipStreamCreateWithFlags(&sh.stream, hipStreamNonBlocking), "hipStreamCreate");
+        sh.rgb.reserve(npix * 3);
+        sh.counts.reserve(npix);
+        if (g == 0) { // the caller's running sums live on the first device
+          sh.rgb.upload(rgbSum, npix * 3, sh.stream);
+          sh.counts.upload(counts, npix, sh.stream);
+        } else {
+          check(hipMemsetAsync(sh.rgb.ptr, 0, npix * 3 * sizeof(double), sh.stream), "memset");
+          check(hipMemsetAsync(sh.counts.ptr, 0, npix * sizeof(uint32_t), sh.stream), "memset");
+        }
+        enqueueRender(*sh.ctx, camera, sh.params, sh.rgb.ptr, sh.counts.ptr, nullptr, sh.stream,
+                      g == 0 && opt.progress ? 20 : 0,
+                      [&](const TraceParams &, uint64_t done, uint64_t totalSamples) {
+                        if (g != 0 || !opt.progress) return false;
+                        check(hipStreamSynchronize(sh.stream), "band");
+                        (void)opt.progress(opt.progress_user, done * n, totalSamples * n);
+                        return false;
+                      });
+      });
+      if (sh.ctx && sh.stream && sh.rgb.ptr && sh.counts.ptr) {
+        int rc;
+        if (sequential)
+          rc = ptw_comm_reduce_framebuffer(comms[g], sh.rgb.ptr, sh.counts.ptr, npix, 0, sh.stream);
+        else
+          rc = ptw_comm_gather_rows(comms[g], sh.rgb.ptr, sh.counts.ptr, params.width, params.height, 0,
+                                    sh.stream);
+        if (rc != PTW_OK && sh.status == PTW_OK) sh.status = rc, sh.error = ptw_last_error();
+        (void)hipSetDevice(sh.device);
+        if (hipStreamSynchronize(sh.stream) != hipSuccess && sh.status == PTW_OK)
+          sh.status = PTW_ERR_HIP, sh.error = "stream synchronise failed after the collective";
+      } else if (sh.status == PTW_OK) {
+        sh.status = PTW_ERR_HIP, sh.error = "device shard was not set up";
+      }
+    });
+  for (auto &t : threads) t.join();
+  for (const DeviceShard &sh : shards)
+    if (sh.status != PTW_OK) throw DeviceError(sh.status, "device " + std::to_string(sh.device) + ": " + sh.error);
+  check(hipSetDevice(shards[0].device), "hipSetDevice");
+  check(hipMemcpy(rgbSum, shards[0].rgb.ptr, npix * 3 * sizeof(double), hipMemcpyDeviceToHost), "D2H");
+  check(hipMemcpy(counts, shards[0].counts.ptr, npix * sizeof(uint32_t), hipMemcpyDeviceToHost), "D2H");
+}
+
+} // namespace
+
+extern "C" int ptw_render_ex(const ptw_scene_view *scene, const ptw_camera *camera,
+                             const ptw_render_params *params, double *rgb_sum, uint32_t *counts,
+                             const ptw_render_options *options) {
+  if (!scene || !camera || !params || !rgb_sum || !counts) return invalid("null pointer");
+  ptw_render_options opt;
+  std::memset(&opt, 0, sizeof opt);
+  if (options) opt = *options;
+  if (opt.num_devices < 0) return invalid("num_devices");
+  PTW_GUARD_BEGIN
+  validate(*params);
+  if (opt.num_devices > 1)
+    renderMulti(*scene, *camera, *params, rgb_sum, counts, opt);
+  else
+    renderSingle(*scene, *camera, *params, rgb_sum, counts, opt);
+  return PTW_OK;
+  PTW_GUARD_END
+}

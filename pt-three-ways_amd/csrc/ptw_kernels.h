@@ -21,13 +21,27 @@ struct TraceParams {
   int32_t uPow2, vPow2;
   int32_t rngPolicy;
   uint32_t passSeedBase; // uint32(seed + first_pass): pass k uses passSeedBase + k
-  uint32_t pixBegin;     // first pixel (row-major index) of this launch's band
+  // A launch covers the band [pixBegin, pixBegin + pixCount) of the shard's LOCAL pixel index
+  // l = localRow * width + x; local row r is image row rowFirst + r * rowStride (PERPIXEL
+  // interleaved-row shards).  SEQUENTIAL renders whole frames: rowFirst = 0, rowStride = 1,
+  // so there local == global.
+  uint32_t pixBegin;
   uint32_t pixCount;     // pixels in the band
   uint32_t npix;         // width * height
   uint32_t npass;
   int32_t firstBand;     // this launch starts the passes' streams (first band of a render)
+  int32_t rowFirst;      // image row of local row 0
+  int32_t rowStride;     // image rows between consecutive local rows (>= 1)
   int32_t padB;
 };
+
+// Global (row-major, full-frame) index of local pixel l.
+__host__ __device__ inline uint32_t globalPixel(const TraceParams &p, uint32_t l) {
+  if (p.rowStride == 1) return static_cast<uint32_t>(p.rowFirst) * static_cast<uint32_t>(p.width) + l;
+  const uint32_t w = static_cast<uint32_t>(p.width);
+  const uint32_t r = l / w, x = l - r * w;
+  return (static_cast<uint32_t>(p.rowFirst) + r * static_cast<uint32_t>(p.rowStride)) * w + x;
+}
 
 struct TraceBuffers {
   const double *triGeom;     // [ntri][9]: v0, e1 = v1 - v0, e2 = v2 - v0
@@ -45,12 +59,16 @@ struct TraceBuffers {
 };
 
 // SEQUENTIAL policy: one workgroup per pass walks the band's pixels in row-major order.
-hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hipStream_t stream);
+// `variant` (may be null) receives the name of the kernel variant that was launched.
+hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hipStream_t stream,
+                                 const char **variant = nullptr);
 // PERPIXEL policy: one lane per (pass, pixel) sample.
-hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipStream_t stream);
-// rgbSum[pix] += sum over passes (in pass order) of stage[pass][pix]; counts[pix] += npass.
-hipError_t launchResolve(const double *stage, uint32_t npass, uint32_t pixBegin, uint32_t pixCount,
-                         double *rgbSum, uint32_t *counts, hipStream_t stream);
+hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipStream_t stream,
+                               const char **variant = nullptr);
+// rgbSum[pix] += sum over passes (in pass order) of stage[pass][l]; counts[pix] += npass, for the
+// local pixels l of the band (pix = globalPixel(p, l)).
+hipError_t launchResolve(const TraceParams &p, const double *stage, double *rgbSum,
+                         uint32_t *counts, hipStream_t stream);
 // Scene::intersect for a batch of rays (known-answer tests).
 hipError_t launchIntersectBatch(const TraceParams &p, const TraceBuffers &b, const double *rays,
                                 uint64_t n, double *hitsOut, hipStream_t stream);

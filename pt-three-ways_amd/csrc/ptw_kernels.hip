@@ -37,6 +37,7 @@
 #include "ptw_device.h"
 #include "ptw_kernels.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <string>
 
@@ -1770,7 +1771,7 @@ __global__ __launch_bounds__(kPixBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
   // consecutive lanes = consecutive pixels of one pass (coalesced stage writes)
   const uint32_t pass = static_cast<uint32_t>(gid / p.pixCount);
   const uint32_t i = static_cast<uint32_t>(gid % p.pixCount);
-  const uint32_t pix = p.pixBegin + i;
+  const uint32_t pix = globalPixel(p, p.pixBegin + i);
 
   PixCtx ctx;
   ctx.p = &p;
@@ -1847,7 +1848,7 @@ __global__ __launch_bounds__(kPix2Block) __attribute__((amdgpu_waves_per_eu(4, 4
   auto beginSample = [&]() {
     pass = static_cast<uint32_t>(sample / p.pixCount);
     pixIdx = static_cast<uint32_t>(sample % p.pixCount);
-    const uint32_t pix = p.pixBegin + pixIdx;
+    const uint32_t pix = globalPixel(p, p.pixBegin + pixIdx);
     rng.seed(p.passSeedBase + pass, pix);
     nwords = 0;
     auto draw = [&]() {
@@ -1871,7 +1872,7 @@ __global__ __launch_bounds__(kPix2Block) __attribute__((amdgpu_waves_per_eu(4, 4
   auto finishSample = [&](d3 L) {
     double *out = stage + (static_cast<size_t>(pass) * p.pixCount + pixIdx) * 3;
     out[0] = L.x, out[1] = L.y, out[2] = L.z;
-    if (words) words[static_cast<size_t>(pass) * p.npix + p.pixBegin + pixIdx] = nwords;
+    if (words) words[static_cast<size_t>(pass) * p.npix + globalPixel(p, p.pixBegin + pixIdx)] = nwords;
     sample = atomicAdd(sampleQueue, 1ull);
     active = sample < total;
   };
@@ -2089,18 +2090,19 @@ __global__ __launch_bounds__(kPix2Block) __attribute__((amdgpu_waves_per_eu(4, 4
 // -----------------------------------------------------------------------------------------
 // resolve: pass-ordered accumulation into the ArrayOutput-shaped running sums.
 // -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void resolveKernel(const double *__restrict__ stage,
-                                                     uint32_t npass, uint32_t pixBegin,
-                                                     uint32_t pixCount, double *__restrict__ rgbSum,
+__global__ __launch_bounds__(256) void resolveKernel(const TraceParams p,
+                                                     const double *__restrict__ stage,
+                                                     double *__restrict__ rgbSum,
                                                      uint32_t *__restrict__ counts) {
-  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; // element = pixel * 3 + channel
-  const uint32_t n = pixCount * 3;
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; // element = local pixel * 3 + channel
+  const uint32_t n = p.pixCount * 3;
   if (e >= n) return;
-  const size_t base = static_cast<size_t>(pixBegin) * 3 + e;
+  const uint32_t l = e / 3, c = e - l * 3;
+  const size_t base = static_cast<size_t>(globalPixel(p, p.pixBegin + l)) * 3 + c;
   double acc = rgbSum[base];
-  for (uint32_t k = 0; k < npass; ++k) acc += stage[static_cast<size_t>(k) * n + e];
+  for (uint32_t k = 0; k < p.npass; ++k) acc += stage[static_cast<size_t>(k) * n + e];
   rgbSum[base] = acc;
-  if (e < pixCount) counts[pixBegin + e] += npass;
+  if (e < p.pixCount) counts[globalPixel(p, p.pixBegin + e)] += p.npass;
 }
 
 // -----------------------------------------------------------------------------------------
@@ -2175,9 +2177,17 @@ __global__ __launch_bounds__(64) void rngKatKernel(int rngPolicy,
 
 constexpr size_t kLdsTableBudget = 150 * 1024; // bytes of LDS we are willing to spend on tables
 
+// Name of the variant the last launch*() call of this thread picked (reported through
+// ptw_kernel_stats so that callers do not have to re-derive the dispatch rules).
+thread_local const char *tlsVariant = "";
+thread_local char tlsVariantBuf[64];
+
 template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false>
 hipError_t launchSeq(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
   auto kernel = traceSequential<SLOTS, WAVES, LDS_TABLES, REG>;
+  std::snprintf(tlsVariantBuf, sizeof tlsVariantBuf, "traceSequential<%d,%d,%s,%s>", SLOTS, WAVES,
+                LDS_TABLES ? "lds" : "global", REG ? "reg" : "stack");
+  tlsVariant = tlsVariantBuf;
   const size_t lds = seqLdsBytes(WAVES, p.maxDepth, LDS_TABLES, p.ntri, p.nmat, p.nsph);
   if (lds > 48 * 1024) { // per launch: the attribute belongs to the current device's copy of the kernel
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
@@ -2200,6 +2210,7 @@ hipError_t launchSeqAuto(const TraceParams &p, const TraceBuffers &b, hipStream_
 }
 
 hipError_t launchSeqSpec(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
+  tlsVariant = "traceSequentialSpec";
   const size_t lds = specLdsBytes(p.ntri, p.nmat, p.nsph);
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(traceSequentialSpec),
@@ -2215,7 +2226,19 @@ hipError_t launchSeqSpec(const TraceParams &p, const TraceBuffers &b, hipStream_
 
 } // namespace
 
-hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
+namespace {
+hipError_t dispatchSequential(const TraceParams &p, const TraceBuffers &b, hipStream_t stream);
+}
+
+hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hipStream_t stream,
+                                 const char **variant) {
+  const hipError_t e = dispatchSequential(p, b, stream);
+  if (variant) *variant = tlsVariant;
+  return e;
+}
+
+namespace {
+hipError_t dispatchSequential(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
   const uint32_t n = p.ntri;
   // Smallest configuration that keeps every triangle resident in VGPRs.  Up to 128 triangles
   // one wave does everything.  Beyond that 7 worker waves + 1 master wave = 8 waves = 2 per SIMD
@@ -2251,13 +2274,16 @@ hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hi
   if (n <= 3584) return launchSeq<8, 7, false>(p, b, stream);
   return launchSeq<12, 7, false>(p, b, stream); // beyond 5376 the tail is streamed from memory
 }
+} // namespace
 
-hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
+hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipStream_t stream,
+                               const char **variant) {
   // Small scenes are shading-bound: the lock-step kernel wins.  Larger scenes are bound by the
   // nearest-hit search, where the persistent kernel's lane re-use pays.  PTW_PIX_KERNEL
   // (legacy|persistent) overrides for A/B runs.
   static const char *forced = std::getenv("PTW_PIX_KERNEL");
   const bool persistent = forced ? std::string(forced) == "persistent" : p.ntri >= 128;
+  if (variant) *variant = persistent ? "tracePerPixelPersistent" : "tracePerPixel";
   if (persistent) {
     const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
     int dev = 0, cus = 256;
@@ -2285,11 +2311,11 @@ hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipS
   return hipGetLastError();
 }
 
-hipError_t launchResolve(const double *stage, uint32_t npass, uint32_t pixBegin, uint32_t pixCount,
-                         double *rgbSum, uint32_t *counts, hipStream_t stream) {
-  const uint32_t n = pixCount * 3;
-  hipLaunchKernelGGL(resolveKernel, dim3((n + 255) / 256), dim3(256), 0, stream, stage, npass,
-                     pixBegin, pixCount, rgbSum, counts);
+hipError_t launchResolve(const TraceParams &p, const double *stage, double *rgbSum,
+                         uint32_t *counts, hipStream_t stream) {
+  const uint32_t n = p.pixCount * 3;
+  hipLaunchKernelGGL(resolveKernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, stage, rgbSum,
+                     counts);
   return hipGetLastError();
 }
 

@@ -16,7 +16,6 @@
 #include <iostream>
 #include <random>
 #include <string>
-#include <thread>
 #include <vector>
 
 namespace {
@@ -188,74 +187,39 @@ int main(int argc, const char *argv[]) {
   out.counts.assign(static_cast<size_t>(o.params.width) * o.params.height, 0u);
 
   const auto startTime = std::chrono::system_clock::now();
-  int rc = PTW_OK;
   Progress progress;
+  // --save-every (main.cpp:331-343): the reference's updateFunc re-saves the running output when
+  // the interval has elapsed.  Here the library hands the running framebuffer back between its
+  // launches (ptw_update_fn) inside ONE render: one context, one scene upload, every pass of a
+  // band in one launch.
+  struct Saver {
+    Output *out;
+    std::chrono::system_clock::time_point next;
+    int every;
+  } saver{&out, startTime + std::chrono::seconds(o.saveEvery), o.saveEvery};
+  auto onUpdate = [](void *user, uint64_t done, uint64_t total, const double *, const uint32_t *) -> int {
+    auto *sv = static_cast<Saver *>(user);
+    const auto now = std::chrono::system_clock::now();
+    if (now > sv->next && done < total) { // the buffers handed in are the caller's own (out)
+      save(*sv->out);
+      sv->next = now + std::chrono::seconds(sv->every);
+    }
+    return 0;
+  };
+  ptw_render_options ro;
+  std::memset(&ro, 0, sizeof ro);
+  ro.progress = onProgress;
+  ro.progress_user = &progress;
   if (o.gpus > 1) {
-    // One host thread per device, each with its own context (ptw_render creates one): device d
-    // renders a contiguous range of the passes - the reference's own decomposition, one task per
-    // pass merged with ArrayOutput::operator+= (src/dod/Scene.cpp:208-246) - into its own
-    // buffers; the partial frames are added in device order.
-    struct Shard {
-      std::vector<double> rgbSum;
-      std::vector<uint32_t> counts;
-      int rc = PTW_OK;
-      std::string error;
-    };
-    const int total = o.params.samples_per_pixel;
-    const bool shareDevice = std::getenv("PTW_CLI_SHARE_DEVICE") != nullptr; // tests on a 1-GPU box
-    std::vector<Shard> shards(static_cast<size_t>(o.gpus));
-    std::vector<std::thread> threads;
-    for (int g = 0; g < o.gpus; ++g) {
-      const int base = total / o.gpus, extra = total % o.gpus;
-      const int first = g * base + std::min(g, extra), count = base + (g < extra ? 1 : 0);
-      threads.emplace_back([&, g, first, count] {
-        Shard &sh = shards[static_cast<size_t>(g)];
-        sh.rgbSum.assign(out.rgbSum.size(), 0.0);
-        sh.counts.assign(out.counts.size(), 0u);
-        if (count == 0) return;
-        ptw_render_params part = o.params;
-        part.device = o.params.device + (shareDevice ? 0 : g);
-        part.first_pass = o.params.first_pass + first;
-        part.samples_per_pixel = count;
-        sh.rc = ptw_render(&view, &camera, &part, sh.rgbSum.data(), sh.counts.data(), nullptr, nullptr);
-        if (sh.rc != PTW_OK) sh.error = ptw_last_error(); // thread-local: copy it out here
-      });
-    }
-    for (auto &t : threads) t.join();
-    std::string firstError;
-    for (const Shard &sh : shards) {
-      if (sh.rc != PTW_OK && rc == PTW_OK) rc = sh.rc, firstError = sh.error;
-      for (size_t i = 0; i < out.rgbSum.size(); ++i) out.rgbSum[i] += sh.rgbSum[i];
-      for (size_t i = 0; i < out.counts.size(); ++i) out.counts[i] += sh.counts[i];
-    }
-    if (rc != PTW_OK) {
-      std::cerr << "render failed: " << firstError << "\n";
-      ptw_scene_destroy(scene);
-      return 1;
-    }
+    // The passes (SEQUENTIAL) or the interleaved image rows (PERPIXEL) are spread over the
+    // devices and merged with one RCCL collective on the devices (ptw_render_ex).
+    ro.num_devices = o.gpus;
+    ro.share_device = std::getenv("PTW_CLI_SHARE_DEVICE") != nullptr; // tests on a 1-GPU box
   } else if (o.saveEvery > 0 && o.params.samples_per_pixel > 1) {
-    // --save-every (main.cpp:331-343): render in pass chunks, re-saving the running sum when
-    // the interval has elapsed.  Chunks continue the same pass sequence through first_pass.
-    auto nextSave = startTime + std::chrono::seconds(o.saveEvery);
-    const int total = o.params.samples_per_pixel;
-    const int chunk = std::max(1, total / 8);
-    for (int first = 0; first < total && rc == PTW_OK; first += chunk) {
-      ptw_render_params part = o.params;
-      part.first_pass = o.params.first_pass + first;
-      part.samples_per_pixel = std::min(chunk, total - first);
-      rc = ptw_render(&view, &camera, &part, out.rgbSum.data(), out.counts.data(), nullptr, nullptr);
-      if (rc == PTW_OK)
-        onProgress(&progress, static_cast<uint64_t>(first + part.samples_per_pixel), total);
-      const auto now = std::chrono::system_clock::now();
-      if (rc == PTW_OK && now > nextSave && first + chunk < total) {
-        save(out);
-        nextSave = now + std::chrono::seconds(o.saveEvery);
-      }
-    }
-  } else {
-    rc = ptw_render(&view, &camera, &o.params, out.rgbSum.data(), out.counts.data(), onProgress,
-                    &progress);
+    ro.update = onUpdate;
+    ro.update_user = &saver;
   }
+  const int rc = ptw_render_ex(&view, &camera, &o.params, out.rgbSum.data(), out.counts.data(), &ro);
   const auto endTime = std::chrono::system_clock::now();
   ptw_scene_destroy(scene);
   if (rc != PTW_OK) {

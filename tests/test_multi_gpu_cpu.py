@@ -1,6 +1,7 @@
-"""CPU (gloo, world_size 2): the multi-GPU sharding + the single framebuffer collective, with
-the oracle standing in for the device renderer.  Checks that pass-sharding (SEQUENTIAL) and
-row-sharding (PERPIXEL) followed by reduce_framebuffer reproduce the single-process render."""
+"""CPU (gloo, world_size 2 and 3): the multi-GPU sharding + the single framebuffer collective, with
+the oracle standing in for the device renderer.  Checks that pass-sharding (SEQUENTIAL) followed
+by reduce_framebuffer and interleaved-row sharding (PERPIXEL) followed by gather_rows reproduce
+the single-process render."""
 import os
 import sys
 from pathlib import Path
@@ -32,23 +33,28 @@ def _worker(rank, world, port, policy, out_dir):
         params = pkg.default_params(width=w, height=h, samples_per_pixel=count, first_pass=first,
                                     seed=3, rng_policy=policy)
     else:
-        r0, r1 = sharding.row_shard(rank, world, h)
         params = pkg.default_params(width=w, height=h, samples_per_pixel=total, seed=3,
-                                    rng_policy=policy, row_begin=r0, row_end=r1)
+                                    rng_policy=policy, **sharding.interleaved_rows(rank, world))
     rgb, cnt, _, _ = ob.oracle_render(scene.view(), cam, params, threads=1, want_words=False)
     t_rgb = torch.from_numpy(rgb)
     t_cnt = torch.from_numpy(cnt.astype(np.int32))
-    sharding.reduce_framebuffer(t_rgb, t_cnt, dst=0)
+    if policy == pkg.RNG_SEQUENTIAL:
+        sharding.reduce_framebuffer(t_rgb, t_cnt, dst=0)
+    else:
+        # only the owned rows were rendered
+        assert int((t_cnt.sum(dim=1) > 0).sum()) == sharding.rows_owned(rank, world, h)
+        sharding.gather_rows(t_rgb, t_cnt, dst=0)
     if rank == 0:
         np.save(Path(out_dir) / f"rgb_{policy}.npy", t_rgb.numpy())
         np.save(Path(out_dir) / f"cnt_{policy}.npy", t_cnt.numpy())
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("policy", [0, 1])
-def test_two_rank_sharding_matches_single_process(pkg, ob, tmp_path, policy):
-    port = 29500 + (os.getpid() % 2000) + policy
-    mp.spawn(_worker, args=(2, port, policy, str(tmp_path)), nprocs=2, join=True)
+def test_sharding_matches_single_process(pkg, ob, tmp_path, policy, world):
+    port = 29500 + (os.getpid() % 2000) + policy + 2 * world
+    mp.spawn(_worker, args=(world, port, policy, str(tmp_path)), nprocs=world, join=True)
     rgb = np.load(tmp_path / f"rgb_{policy}.npy")
     cnt = np.load(tmp_path / f"cnt_{policy}.npy")
     scene = pkg.Scene()
@@ -62,6 +68,22 @@ def test_two_rank_sharding_matches_single_process(pkg, ob, tmp_path, policy):
         assert np.max(np.abs(rgb - ref_rgb) / np.maximum(np.abs(ref_rgb), 1.0)) < 1e-14
 
 
+def test_oracle_row_windows(pkg, ob):
+    """The row-window contract of include/ptw.h as the oracle implements it: (0,0) = all rows,
+    begin == end != 0 = an empty shard, stride/phase = interleaved rows."""
+    scene = pkg.Scene()
+    cam = scene.build_named("cornell", 6, 7)
+    def counts(**kw):
+        p = pkg.default_params(width=6, height=7, samples_per_pixel=2, seed=3, rng_policy=1, **kw)
+        return ob.oracle_render(scene.view(), cam, p, threads=1, want_words=False)[1]
+    assert (counts() == 2).all()
+    assert (counts(row_begin=3, row_end=3) == 0).all()
+    c = counts(row_stride=3, row_phase=1)
+    assert [int(r[0]) for r in c] == [0, 2, 0, 0, 2, 0, 0]
+    c = counts(row_begin=2, row_end=6, row_stride=2, row_phase=1)
+    assert [int(r[0]) for r in c] == [0, 0, 0, 2, 0, 2, 0]
+
+
 def test_shard_arithmetic(pkg):
     import importlib
     s = importlib.import_module("pt_three_ways_amd.sharding")
@@ -73,4 +95,5 @@ def test_shard_arithmetic(pkg):
             rows = [s.row_shard(r, world, total) for r in range(world)]
             assert rows[0][0] == 0 and rows[-1][1] == total
             assert all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
+            assert sum(s.rows_owned(r, world, total) for r in range(world)) == total
     assert s.weak_pass_shard(3, 256) == (768, 256)
