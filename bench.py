@@ -1,21 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py — the reference's headline metric on MI355X: Msamples/s of the DoD radiance path.
+"""bench.py — the reference's headline metric on MI355X: Msamples/s of the DoD radiance path,
+and the metric's second half: per-channel RMSE against the DoD reference on the full frame.
 
     python bench.py --gpus N --steps K --warmup W            (N = 1)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[1]): CornellBox-Original.obj, 1024x1024, 256 samples per pixel,
-maxDepth 5, 4x4 first-bounce fan-out, seed 1.  One STEP = one complete render of that frame on
-every rank: 1024*1024*256 = 268,435,456 samples per GPU per step, scene and framebuffer
-resident in HBM (the scene upload happens once, outside the timed region).
+maxDepth 5, 4x4 first-bounce fan-out, seed 1.  One STEP = one complete render of that frame:
+1024*1024*256 = 268,435,456 samples, scene and framebuffer resident in HBM (the scene upload
+happens once, outside the timed region).
 
 RNG policy of the headline number: SEQUENTIAL - the reference's own per-pass std::mt19937
-streams, so the image equals the reference DoD renderer's at matched seed (tests/ prove it
-against the oracle).  Pixels of a pass are serially dependent under that policy, so N GPUs shard
-the PASSES (rank r renders passes [r*spp, (r+1)*spp) of the same frame, i.e. seeds seed+r*spp..)
-and one RCCL reduce(sum) of the fp64 framebuffer merges them - weak scaling: per-GPU work fixed,
-total samples = N * 268M.  The PERPIXEL policy (tile-shardable, not seed-matched) is measured
-in the same run and reported beside it under "perpixel_policy".
+streams, so the image equals the reference DoD renderer's at matched seed; after the timed
+region the frame is rendered once more with per-sample RNG word counts and compared with the
+reference's own code (oracle/_ref: the reference's sources compiled where they lie) run on all
+host cores: `rmse_vs_ref`, `max_abs_diff`, `pixels_bit_identical`, `samples_word_count_differs`.
+
+N > 1 (one process per GPU): STRONG scaling of the same frame by default (`--scaling strong`):
+  sequential  the 256 passes are split over the ranks (pixels of a pass are serially dependent
+              under this policy, passes are independent - the reference's own decomposition,
+              src/dod/Scene.cpp:208-246) and ONE RCCL reduce(sum) of the fp64 framebuffer merges
+              them (ptw_comm_reduce_framebuffer: RCCL behind the C ABI);
+  perpixel    the image rows are interleaved over the ranks (row y -> rank y % N) and ONE RCCL
+              gather of the rows assembles the frame (ptw_comm_gather_rows).
+`--scaling weak` keeps 256 passes per GPU with distinct seeds (N x the samples).
 
 Prints ONE JSON line on rank 0.
 """
@@ -26,17 +34,18 @@ import json
 import os
 import sys
 import time
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402  (first: one HIP runtime per process, see pt-three-ways_amd/__init__.py)
 import torch.distributed as dist  # noqa: E402
 
 import __graft_entry__ as entry  # noqa: E402
 
-SHARDING = None
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak: 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FLOP_PER_TRI_TEST = 45.0       # Moller-Trumbore incl. 1 division
@@ -45,6 +54,8 @@ FLOP_PER_SPHERE_TEST = 19.0
 # by the resolve kernel; the framebuffer read-modify-write (24+24+4+4 B per pixel per band) is
 # amortised over the passes of a launch.  SURVEY.md section 8(d)(ii).
 HBM_BYTES_PER_SAMPLE_TRACE = 24.0
+# CPU sample sizes per scene (cornell at full frame size, sub-frames for the others)
+CPU_SAMPLE_FRAME = {"cornell": 1024, "suzanne": 256, "ce": 64}
 
 
 def parse_args():
@@ -58,46 +69,124 @@ def parse_args():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--policy", choices=["sequential", "perpixel"], default="sequential")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: split the frame's work over the ranks (strong) or give every rank "
+                         "--spp passes of its own (weak)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the full-frame comparison with the reference (rmse_vs_ref)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the extra measurement of the other RNG policy")
     ap.add_argument("--cpu-threads", type=int, default=6)
+    ap.add_argument("--cpu-frame", type=int, default=0,
+                    help="edge of the square frame of the CPU legs (0: per scene, cornell 1024)")
     return ap.parse_args()
 
 
-def timed_render(ctx, cam, params, rgb, cnt, steps, use_dist, reduce_to_root):
-    """Times `steps` full renders (+ the framebuffer reduce under torch.distributed)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+class Shard:
+    """What this rank renders and how the frame is merged afterwards."""
+
+    def __init__(self, pkg, sharding, args, rank, world, local_rank, use_dist):
+        self.pkg, self.world, self.rank = pkg, world, rank
+        self.policy = pkg.RNG_SEQUENTIAL if args.policy == "sequential" else pkg.RNG_PERPIXEL
+        extra = {}
+        spp = args.spp
+        first_pass = 0
+        self.merge = None
+        if world > 1 or use_dist:   # under torch.distributed.run even one rank takes the collective path
+            if self.policy == pkg.RNG_PERPIXEL:
+                extra = sharding.interleaved_rows(rank, world)
+                self.merge = "gather_rows"
+                self.total_spp = args.spp
+                self.scaling = "strong"
+                self.parallelism = (f"image rows interleaved over {world} GPUs (row y -> rank y % {world}) "
+                                    "+ one RCCL gather of the rows (ptw_comm_gather_rows)")
+            elif args.scaling == "strong":
+                first_pass, spp = sharding.pass_shard(rank, world, args.spp)
+                self.merge = "reduce"
+                self.total_spp = args.spp
+                self.scaling = "strong"
+                self.parallelism = (f"{args.spp} passes split over {world} GPUs + one RCCL reduce(sum) of the "
+                                    "fp64 framebuffer (ptw_comm_reduce_framebuffer)")
+            else:
+                first_pass, spp = sharding.weak_pass_shard(rank, args.spp)
+                self.merge = "reduce"
+                self.total_spp = args.spp * world
+                self.scaling = "weak"
+                self.parallelism = (f"{args.spp} passes per GPU x {world} GPUs (distinct seeds) + one RCCL "
+                                    "reduce(sum) of the fp64 framebuffer (ptw_comm_reduce_framebuffer)")
+        else:
+            self.total_spp = args.spp
+            self.scaling = "strong" if args.scaling == "strong" else "weak"
+            self.parallelism = "single GPU"
+        self.params = pkg.default_params(width=args.width, height=args.height, samples_per_pixel=spp,
+                                         seed=args.seed, first_pass=first_pass, rng_policy=self.policy,
+                                         device=local_rank, **extra)
+        self.comm = sharding.FrameComm(pkg, local_rank) if self.merge else None
+
+    def render_and_merge(self, ctx, cam, rgb, cnt, stream):
+        if self.params.samples_per_pixel > 0:
+            ctx.render(cam, self.params, rgb.data_ptr(), cnt.data_ptr(), 0, stream)
+        if self.merge == "reduce":
+            self.comm.reduce_framebuffer(rgb, cnt, dst=0, stream=stream)
+        elif self.merge == "gather_rows":
+            self.comm.gather_rows(rgb, cnt, dst=0, stream=stream)
+
+
+def timed_steps(shard, ctx, cam, bufs, steps, use_dist):
+    """Times `steps` full renders (+ the framebuffer collective).  The last step accumulates into
+    bufs[-1] (zeroed by the caller, kept for inspection), the others into bufs[0]."""
     stream = torch.cuda.current_stream().cuda_stream
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        ctx.render(cam, params, rgb.data_ptr(), cnt.data_ptr(), 0, stream)
-        if reduce_to_root:
-            SHARDING.reduce_framebuffer(rgb, cnt, dst=0)  # the one data-path collective (RCCL)
+    for i in range(steps):
+        rgb, cnt = bufs[-1] if i == steps - 1 else bufs[0]
+        shard.render_and_merge(ctx, cam, rgb, cnt, stream)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     return time.perf_counter() - t0
 
 
-def cpu_baseline(pkg, scene_name, threads):
-    """The CPU path timed on this box's host cores on a bounded sample of the same workload."""
-    sys.path.insert(0, str(ROOT / "tests"))
-    import oracle_binding as ob  # test infrastructure, used here only as the reported baseline
+# ---- CPU legs: the reference's own code on this box's host cores ----------------------------
+def ref_passes(ob, scene_name, view, params, passes, threads, want_words, on_pass=None):
+    """Runs the reference's pass loop (Scene.cpp:209-219, oracle/_ref) for the given pass indices on
+    `threads` host threads (one full-frame pass per thread at a time, like the reference's
+    std::async tasks) and hands every pass to `on_pass(pass_index, radiance, words)` IN PASS ORDER."""
+    rs = ob.RefScene(view, lib=ob.ref_fast)
+    desc = ob.cam_desc(**ob.SCENE_CAMERAS[scene_name])
 
-    w = h = 384
-    passes = 2 * threads
+    def one(k):
+        return k, rs.render_pass(desc, params, k, want_words=want_words)
+
+    with ThreadPoolExecutor(max_workers=threads) as pool:  # ctypes calls release the GIL
+        for k, (rad, words) in pool.map(one, passes):      # map() yields in submission order
+            if on_pass:
+                on_pass(k, rad, words)
+
+
+def cpu_leg(pkg, ob, scene_name, threads, passes, frame):
+    """One timed CPU leg: `passes` full-frame passes of a frame x frame image on `threads` threads."""
     scene = pkg.Scene()
-    cam = scene.build_named(scene_name, w, h)
-    params = pkg.default_params(width=w, height=h, samples_per_pixel=passes, seed=1)
+    cam = scene.build_named(scene_name, frame, frame)
+    params = pkg.default_params(width=frame, height=frame, samples_per_pixel=passes, seed=1)
+    n = frame * frame * passes
     if ob.ref_fast is not None and scene_name in ob.SCENE_CAMERAS:
         kind = "reference"
-        rs = ob.RefScene(scene.view(), lib=ob.ref_fast)
-        desc = ob.cam_desc(**ob.SCENE_CAMERAS[scene_name])
         t0 = time.perf_counter()
-        rs.render(desc, params, threads=threads)
+        ref_passes(ob, scene_name, scene.view(), params, list(range(passes)), threads, False)
         dt = time.perf_counter() - t0
         what = ("reference dod::Scene::radiance + Camera::randomRay compiled from /root/reference/src "
                 "with -O2 -march=x86-64-v3 -funsafe-math-optimizations (oracle/_ref), pass loop of "
@@ -109,12 +198,65 @@ def cpu_baseline(pkg, scene_name, threads):
         ob.oracle_render(scene.view(), cam, params, threads=threads, want_words=False, lib=lib)
         dt = time.perf_counter() - t0
         what = "oracle/ptw_oracle.c (C restatement) built with the reference's optimisation flags"
-    n = w * h * passes
     return {
         "value": n / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": kind,
-        "sample": f"{scene_name} {w}x{h}, {passes} full-frame passes on {threads} threads "
+        "sample": f"{scene_name} {frame}x{frame}, {passes} full-frame passes on {threads} threads "
                   f"(one pass per thread at a time, as the reference); {what}; "
-                  f"{n} samples in {dt:.1f} s; host has {os.cpu_count()} logical cores",
+                  f"{n} samples in {dt:.1f} s; host: {cpu_model()}, {os.cpu_count()} logical cores",
+    }
+
+
+def parity_vs_reference(pkg, ob, ctx, cam, view, args, threads):
+    """The metric's second half on the FULL frame: renders the frame once more on the GPU with
+    per-sample RNG word counts, runs the reference's own code for the same passes on all host
+    cores, and compares every pixel and every sample's word count."""
+    w, h, spp = args.width, args.height, args.spp
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=args.seed,
+                                rng_policy=pkg.RNG_SEQUENTIAL)
+    rgb = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+    cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    words = torch.zeros((spp, h, w), dtype=torch.int32, device="cuda")
+    ctx.render(cam, params, rgb.data_ptr(), cnt.data_ptr(), words.data_ptr(),
+               torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    gpu_sum = rgb.cpu().numpy()
+    gpu_cnt = cnt.cpu().numpy().astype(np.uint32)
+
+    ref_sum = np.zeros((h, w, 3))
+    stats = {"word_mismatch": 0, "words_total": 0}
+
+    def on_pass(k, rad, wd):   # pass order: output += pass (ArrayOutput.cpp:48-56)
+        np.add(ref_sum, rad, out=ref_sum)
+        gw = words[k].cpu().numpy().astype(np.uint32)
+        stats["word_mismatch"] += int(np.count_nonzero(gw != wd))
+        stats["words_total"] += int(wd.sum(dtype=np.uint64))
+
+    t0 = time.perf_counter()
+    ref_passes(ob, args.scene, view, params, list(range(spp)), threads, True, on_pass)
+    dt = time.perf_counter() - t0
+    del words
+    mean_gpu = gpu_sum / np.maximum(gpu_cnt, 1)[..., None]
+    mean_ref = ref_sum / float(spp)
+    diff = mean_gpu - mean_ref
+    rmse = np.sqrt(np.mean(diff * diff, axis=(0, 1)))
+    identical = np.all(gpu_sum == ref_sum, axis=2)
+    return {
+        "rmse_vs_ref": [float(x) for x in rmse],
+        "max_abs_diff": float(np.max(np.abs(diff))),
+        "pixels_bit_identical": int(identical.sum()), "pixels": int(w * h),
+        "samples_word_count_differs": stats["word_mismatch"], "samples": int(w) * h * spp,
+        "counts_equal": bool(np.all(gpu_cnt == spp)),
+        "mean_words_per_sample": stats["words_total"] / float(w * h * spp),
+        "reference": "oracle/_ref: the reference's own src/dod/Scene.cpp + src/math + ArrayOutput compiled "
+                     "where they lie (-O2 -march=x86-64-v3 -funsafe-math-optimizations), pass loop of "
+                     "Scene.cpp:209-219, passes added in pass order",
+        "compared": "per-pixel means (sum / count, linear fp64) of the full frame; fp64 sums bitwise; "
+                    "RNG words consumed by every (pass, pixel) sample",
+    }, {
+        "value": w * h * spp / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "reference",
+        "sample": f"{args.scene} {w}x{h}, all {spp} passes on {threads} threads (the full headline frame, "
+                  f"the parity reference of this run); {w * h * spp} samples in {dt:.1f} s; host: "
+                  f"{cpu_model()}, {os.cpu_count()} logical cores",
     }
 
 
@@ -123,7 +265,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # launched by torch.distributed.run (even with one rank): one process per GPU over RCCL
+    # launched by torch.distributed.run (even with one rank): one process per GPU
     use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -139,37 +281,37 @@ def main():
 
     pkg = entry.load_package()
     import importlib
-    global SHARDING
-    SHARDING = importlib.import_module("pt_three_ways_amd.sharding")
+    sharding = importlib.import_module("pt_three_ways_amd.sharding")
     w, h, spp = args.width, args.height, args.spp
     scene = pkg.Scene()
     cam = scene.build_named(args.scene, w, h)
     view = scene.view()
     ntri, nsph = view.num_triangles, view.num_spheres
     ctx = pkg.Context(local_rank)
+    t0 = time.perf_counter()
     ctx.set_scene(scene)
+    scene_upload_ms = (time.perf_counter() - t0) * 1e3
 
-    policy = pkg.RNG_SEQUENTIAL if args.policy == "sequential" else pkg.RNG_PERPIXEL
-    # weak scaling by passes: rank r renders passes [r*spp, (r+1)*spp)
-    first_pass, _ = SHARDING.weak_pass_shard(rank, spp)
-    params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=args.seed,
-                                first_pass=first_pass, rng_policy=policy, device=local_rank)
-    rgb = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
-    cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    shard = Shard(pkg, sharding, args, rank, world, local_rank, use_dist)
+    policy = shard.policy
+    scratch = (torch.zeros((h, w, 3), dtype=torch.float64, device="cuda"),
+               torch.zeros((h, w), dtype=torch.int32, device="cuda"))
+    final = (torch.zeros_like(scratch[0]), torch.zeros_like(scratch[1]))
 
     # untimed: load code objects / allocate staging with a tiny render, then the W warm-up steps
     tiny = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=args.seed,
                               rng_policy=pkg.RNG_PERPIXEL, row_begin=0, row_end=1)
-    ctx.render(cam, tiny, rgb.data_ptr(), cnt.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    ctx.render(cam, tiny, scratch[0].data_ptr(), scratch[1].data_ptr(), 0,
+               torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     if args.warmup > 0:
-        timed_render(ctx, cam, params, rgb, cnt, args.warmup, use_dist, use_dist)
-    rgb.zero_()
-    cnt.zero_()
+        timed_steps(shard, ctx, cam, [scratch], args.warmup, use_dist)
+    scratch[0].zero_()
+    scratch[1].zero_()
 
     ctx.enable_stats(True)
     ctx.stats(reset=True)
-    elapsed = timed_render(ctx, cam, params, rgb, cnt, args.steps, use_dist, use_dist)
+    elapsed = timed_steps(shard, ctx, cam, [scratch, final], args.steps, use_dist)
     stats = ctx.stats(reset=True)
     ctx.enable_stats(False)
     if use_dist:
@@ -177,7 +319,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    samples_per_step = w * h * spp * world
+    samples_per_step = w * h * shard.total_spp
     total_samples = samples_per_step * args.steps
     value = total_samples / elapsed / 1e6
 
@@ -191,38 +333,54 @@ def main():
         flop_per_ray = ntri * FLOP_PER_TRI_TEST + nsph * FLOP_PER_SPHERE_TEST
         achieved_tflops = rays_per_launch * flop_per_ray / avg_launch_s / 1e12
         hbm_gbs = samples_per_launch * HBM_BYTES_PER_SAMPLE_TRACE / avg_launch_s / 1e9
+        kernel_variant = stats.trace_kernel.decode() or "unknown"   # reported by the library
         kernel = "traceSequential" if policy == pkg.RNG_SEQUENTIAL else "tracePerPixel"
-        kernel_variant = kernel
-        if policy == pkg.RNG_SEQUENTIAL and ntri <= 64 and nsph <= 64 and os.environ.get("PTW_SEQ_SPEC", "1") != "0":
-            kernel_variant = "traceSequentialSpec"  # the variant launchTraceSequential() picks (ptw_kernels.hip)
-        traffic = None
+        traffic, traffic_source = None, None
         traffic_file = ROOT / "profiles" / "hbm_traffic.json"
         if traffic_file.exists():
             try:
-                rec = json.loads(traffic_file.read_text()).get(f"{kernel}:{args.scene}")
+                table = json.loads(traffic_file.read_text())
+                rec = table.get(f"{kernel_variant}:{args.scene}") or table.get(f"{kernel}:{args.scene}")
                 if rec:
                     traffic = rec["hbm_bytes_per_sample"] * samples_per_launch
+                    traffic_source = ("profiles/hbm_traffic.json (rocprofv3 --pmc passes of an earlier run: "
+                                      f"{rec.get('measured_on', 'see file')}), scaled to this run's samples per launch")
             except Exception:
                 traffic = None
+        fb_bytes = w * h * 28
+        hostbuf = torch.empty(fb_bytes, dtype=torch.uint8).pin_memory()
+        devbuf = torch.empty(fb_bytes, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        devbuf.copy_(hostbuf, non_blocking=False)
+        torch.cuda.synchronize()
+        h2d_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        hostbuf.copy_(devbuf, non_blocking=False)
+        torch.cuda.synchronize()
+        d2h_ms = (time.perf_counter() - t0) * 1e3
         result = {
             "metric": "Msamples/sec CornellBox 1024²@256spp; per-channel RMSE vs DoD ref",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": shard.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "bundled scene (scenes/CornellBox-Original.obj + reference sphere), seed 1",
             "config": {
-                "workload": f"{args.scene} {w}x{h} @ {spp} spp per GPU, maxDepth 5, 4x4 first bounce, "
+                "workload": f"{args.scene} {w}x{h} @ {shard.total_spp} spp, maxDepth 5, 4x4 first bounce, "
                             f"rng_policy={args.policy}",
                 "scene": args.scene, "triangles": ntri, "spheres": nsph, "width": w, "height": h,
-                "spp_per_gpu": spp, "total_spp": spp * world, "rng_policy": args.policy,
-                "parallelism": f"pass-sharded x{world} + RCCL reduce(sum) of the fp64 framebuffer"
-                               if world > 1 else "single GPU",
+                "total_spp": shard.total_spp, "spp_this_rank": int(shard.params.samples_per_pixel),
+                "rng_policy": args.policy, "parallelism": shard.parallelism,
             },
+            "end_to_end_ms_per_step": elapsed / args.steps * 1e3 + scene_upload_ms + h2d_ms + d2h_ms,
+            "end_to_end_note": f"ms_per_step + scene upload incl. per-primitive precompute ({scene_upload_ms:.1f} ms) "
+                               f"+ framebuffer H2D ({h2d_ms:.2f} ms) + D2H ({d2h_ms:.2f} ms, 28 B/pixel each "
+                               "way over PCIe), each measured once in this run; never part of `value`",
             "roofline": {
                 "bound": "valu_fp64", "kernel": kernel_variant,
                 "achieved": achieved_tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tflops / FP64_VALU_PEAK_TFLOPS,
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": avg_launch_s * 1e3, "launches": int(stats.trace_launches),
                 "algorithmic_flop_per_launch": rays_per_launch * flop_per_ray,
                 "rays_per_sample": stats.rays / max(1, stats.samples),
@@ -240,36 +398,59 @@ def main():
         }
 
     # -- the other RNG policy, same workload, same run (N = 1 only) ---------------------------
-    if world == 1 and not args.no_secondary:
-        other = pkg.RNG_PERPIXEL if policy == pkg.RNG_SEQUENTIAL else pkg.RNG_SEQUENTIAL
-        if other == pkg.RNG_PERPIXEL:
-            p2 = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=args.seed,
-                                    rng_policy=other)
-            rgb2 = torch.zeros_like(rgb)
-            cnt2 = torch.zeros_like(cnt)
-            ctx.enable_stats(True)
-            ctx.stats(reset=True)
-            dt2 = timed_render(ctx, cam, p2, rgb2, cnt2, 1, False, False)
-            s2 = ctx.stats(reset=True)
-            ctx.enable_stats(False)
-            fl = s2.rays * (ntri * FLOP_PER_TRI_TEST + nsph * FLOP_PER_SPHERE_TEST)
-            tf = fl / (s2.trace_ms / 1e3) / 1e12
-            result["perpixel_policy"] = {
-                "value": w * h * spp / dt2 / 1e6, "unit": "Msamples/s", "ms_per_step": dt2 * 1e3,
-                "roofline": {"bound": "valu_fp64", "kernel": "tracePerPixel", "achieved": tf,
-                             "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": tf / FP64_VALU_PEAK_TFLOPS,
-                             "avg_launch_ms": s2.trace_ms / max(1, s2.trace_launches)},
-                "note": "same estimator and workload, independent sfc32 stream per (pass, pixel); "
-                        "not seed-matched with the reference; exact vs the oracle under the same policy",
-                "mean_abs_diff_vs_sequential_image":
-                    float((rgb2 / spp - rgb / (spp * args.steps)).abs().mean().item()),
-            }
+    if world == 1 and not args.no_secondary and policy == pkg.RNG_SEQUENTIAL:
+        p2 = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=args.seed,
+                                rng_policy=pkg.RNG_PERPIXEL)
+        rgb2 = torch.zeros_like(final[0])
+        cnt2 = torch.zeros_like(final[1])
+        ctx.enable_stats(True)
+        ctx.stats(reset=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.render(cam, p2, rgb2.data_ptr(), cnt2.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        s2 = ctx.stats(reset=True)
+        ctx.enable_stats(False)
+        fl = s2.rays * (ntri * FLOP_PER_TRI_TEST + nsph * FLOP_PER_SPHERE_TEST)
+        tf = fl / (s2.trace_ms / 1e3) / 1e12
+        result["perpixel_policy"] = {
+            "value": w * h * spp / dt2 / 1e6, "unit": "Msamples/s", "ms_per_step": dt2 * 1e3,
+            "roofline": {"bound": "valu_fp64", "kernel": s2.trace_kernel.decode(), "achieved": tf,
+                         "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / FP64_VALU_PEAK_TFLOPS,
+                         "avg_launch_ms": s2.trace_ms / max(1, s2.trace_launches)},
+            "note": "same estimator and workload, independent sfc32 stream per (pass, pixel); "
+                    "not seed-matched with the reference; exact vs the oracle under the same policy",
+            "mean_abs_diff_vs_sequential_image":
+                float((rgb2 / spp - final[0] / spp).abs().mean().item()),
+        }
+        del rgb2, cnt2
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(pkg, args.scene, args.cpu_threads)
+    if rank == 0 and world == 1 and (not args.no_cpu_baseline or not args.no_parity):
+        sys.path.insert(0, str(ROOT / "tests"))
+        import oracle_binding as ob  # test infrastructure: the checker / the reported baseline only
+        legs = []
+        if not args.no_parity and policy == pkg.RNG_SEQUENTIAL:
+            if ob.ref_fast is not None and args.scene in ob.SCENE_CAMERAS:
+                parity, all_cores_leg = parity_vs_reference(pkg, ob, ctx, cam, view, args,
+                                                            os.cpu_count() or 1)
+                result.update(parity)
+                legs.append(all_cores_leg)
+            else:
+                result["rmse_vs_ref"] = None
+                result["parity_note"] = "oracle/_ref is not built on this box"
+        if not args.no_cpu_baseline:
+            frame = args.cpu_frame or CPU_SAMPLE_FRAME.get(args.scene, 256)
+            six = cpu_leg(pkg, ob, args.scene, args.cpu_threads, 2 * args.cpu_threads, frame)
+            one = cpu_leg(pkg, ob, args.scene, 1, 1, frame)
+            result["cpu_baseline"] = six       # the comparator north_star names: 6 threads
+            legs = [one, six] + legs
+        result["cpu_baseline_legs"] = legs
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if shard.comm:
+        shard.comm.close()
     if use_dist:
         dist.destroy_process_group()
 

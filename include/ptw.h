@@ -220,10 +220,10 @@ int ptw_context_set_scene(ptw_context *ctx, const ptw_scene_view *scene);
 /* Enqueue the render on `hip_stream` (a hipStream_t, NULL = default stream).  d_rgb_sum and
  * d_counts are DEVICE pointers to width*height*3 doubles / width*height uint32 and are
  * accumulated into.  Asynchronous: nothing here waits for the device; the caller synchronises
- * the stream.  A context owns one set of scratch buffers (generator states, staging), so ONE
- * render may be in flight per context: synchronise `hip_stream` before the next
- * ptw_context_render / ptw_context_set_scene on the same context (renders on different
- * contexts are independent).  If d_words is not NULL it receives, per pass and pixel
+ * the stream.  A context owns one set of scratch buffers (generator states, staging): renders
+ * of one context must be enqueued on the SAME stream (they then run one after another in stream
+ * order); to change streams, or before ptw_context_set_scene, synchronise the stream of the
+ * previous render.  Renders on different contexts are independent.  If d_words is not NULL it receives, per pass and pixel
  * ([pass][y][x], uint32), the number of 32-bit RNG words that sample consumed (parity
  * instrumentation; SEQUENTIAL and PERPIXEL). */
 int ptw_context_render(ptw_context *ctx, const ptw_camera *camera,

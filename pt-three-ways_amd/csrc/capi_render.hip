@@ -81,6 +81,7 @@ struct ptw_context {
   // the upload may still be in flight when ptw_context_render returns (one render in flight per
   // context, see include/ptw.h).
   std::vector<uint32_t> hostSeedStates, hostPos;
+  hipEvent_t uploadsDone = nullptr; // recorded after a render's uploads: the host vectors are free again
   const char *traceKernel = ""; // variant name of the last trace launch
 
   bool statsEnabled = false;
@@ -117,7 +118,10 @@ struct ptw_context {
     }
     timed.clear();
   }
-  ~ptw_context() { clearEvents(); }
+  ~ptw_context() {
+    clearEvents();
+    if (uploadsDone) (void)hipEventDestroy(uploadsDone);
+  }
 };
 
 namespace {
@@ -241,12 +245,17 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
 
   if (sequential) {
     // std::mt19937 rng(seed + curSample++), Scene.cpp:211: seed the generators on the host
+    if (ctx.uploadsDone) // an earlier render's upload may still be reading the host vectors
+      check(hipEventSynchronize(ctx.uploadsDone), "hipEventSynchronize");
+    else
+      check(hipEventCreateWithFlags(&ctx.uploadsDone, hipEventDisableTiming), "hipEventCreate");
     ctx.hostSeedStates.resize(static_cast<size_t>(npass) * kMtWords);
     for (uint32_t k = 0; k < npass; ++k)
       seedMt19937(t.passSeedBase + k, &ctx.hostSeedStates[static_cast<size_t>(k) * kMtWords]);
     ctx.mtState.upload(ctx.hostSeedStates.data(), ctx.hostSeedStates.size(), stream);
     ctx.hostPos.assign(npass, kMtDoubles); // 312 = "regenerate before the first draw"
     ctx.mtPos.upload(ctx.hostPos.data(), npass, stream);
+    check(hipEventRecord(ctx.uploadsDone, stream), "hipEventRecord");
     ctx.specState.reserve(static_cast<size_t>(npass) * kSpecStateDoubles);
   }
 
@@ -567,8 +576,15 @@ void renderMulti(const ptw_scene_view &scene, const ptw_camera &camera,
 
   std::vector<DeviceShard> shards(static_cast<size_t>(n));
   std::vector<int32_t> devices(static_cast<size_t>(n));
+  int deviceCount = 0;
+  if (hipGetDeviceCount(&deviceCount) != hipSuccess || deviceCount <= 0)
+    throw DeviceError(PTW_ERR_NO_DEVICE, "no HIP device available (the hip way has no CPU fallback)");
   for (int g = 0; g < n; ++g) {
     devices[g] = opt.share_device ? params.device : (opt.devices ? opt.devices[g] : params.device + g);
+    if (devices[g] < 0 || devices[g] >= deviceCount)
+      throw DeviceError(PTW_ERR_NO_DEVICE, "HIP device ordinal " + std::to_string(devices[g]) +
+                                               " out of range (" + std::to_string(deviceCount) +
+                                               " device(s) visible)");
     DeviceShard &sh = shards[g];
     sh.device = devices[g];
     sh.params = params;

@@ -31,7 +31,8 @@ def _free_port():
 
 
 def test_bench_single_process_line():
-    proc = subprocess.run([sys.executable, str(ROOT / "bench.py"), *SMALL, "--cpu-threads", "2"],
+    proc = subprocess.run([sys.executable, str(ROOT / "bench.py"), *SMALL, "--cpu-threads", "2",
+                           "--cpu-frame", "96"],
                           capture_output=True, text=True, timeout=900, cwd=ROOT)
     r = _json_line(proc)
     assert CONTRACT_KEYS <= set(r)
@@ -45,7 +46,15 @@ def test_bench_single_process_line():
     assert 20 < roof["rays_per_sample"] < 80
     cpu = r["cpu_baseline"]
     assert cpu["value"] > 0 and cpu["cores"] == 2 and cpu["kind"] in ("reference", "port")
+    assert [leg["cores"] for leg in r["cpu_baseline_legs"]][:2] == [1, 2]
     assert r["perpixel_policy"]["value"] > r["value"]
+    assert r["end_to_end_ms_per_step"] > r["ms_per_step"]
+    # the metric's second half: the whole frame against the reference's own code
+    if r.get("rmse_vs_ref") is not None:
+        assert max(r["rmse_vs_ref"]) < 1e-12 and r["max_abs_diff"] < 1e-12
+        assert r["samples_word_count_differs"] == 0 and r["counts_equal"]
+        assert r["pixels_bit_identical"] >= 0.999 * r["pixels"]
+        assert r["cpu_baseline_legs"][-1]["cores"] >= 1
 
 
 def test_bench_under_torchrun_one_rank():
@@ -56,4 +65,12 @@ def test_bench_under_torchrun_one_rank():
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     r = _json_line(proc)
     assert CONTRACT_KEYS <= set(r)
-    assert r["n_gpus"] == 1 and r["scaling"] == "weak" and r["value"] > 0
+    assert r["n_gpus"] == 1 and r["scaling"] == "strong" and r["value"] > 0
+
+
+def test_bench_weak_flag_and_perpixel_policy():
+    proc = subprocess.run([sys.executable, str(ROOT / "bench.py"), *SMALL, "--scaling", "weak", "--policy",
+                           "perpixel", "--no-cpu-baseline", "--no-parity"],
+                          capture_output=True, text=True, timeout=900, cwd=ROOT)
+    r = _json_line(proc)
+    assert r["scaling"] == "weak" and r["roofline"]["kernel"] == "tracePerPixel"
