@@ -75,6 +75,8 @@ struct ptw_context {
   DeviceArray<uint32_t> mtState, mtPos;
   DeviceArray<double> stage;
   DeviceArray<unsigned long long> sampleQueue; // work counter of the persistent kernel
+  DeviceArray<unsigned long long> countHist; // traceSequentialWide: committed sub-samples by levels reached
+  DeviceArray<unsigned char> wideCands;      // traceSequentialWide: the candidate set of the current band
   DeviceArray<unsigned long long> rays; // per-pass intersect() counters, accumulated
   uint64_t rayCarry = 0;                // counts folded in when `rays` had to grow
   // Host sources of the asynchronous uploads of a render; they live in the context because
@@ -232,9 +234,15 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   if (minBands > 1) bandPix = std::min<uint64_t>(bandPix, (pixTotal + minBands - 1) / minBands);
   bandPix = std::max<uint64_t>(bandPix, 64);
   bandPix = std::min<uint64_t>(bandPix, pixTotal);
+  // The wide sequential kernel picks its speculation candidates per band from the statistics of
+  // the band before: give it a short first band to measure on and at least eight bands, so that
+  // the set follows the image from top to bottom.
+  const bool adaptive = sequential && wideKernelApplies(t) && pixTotal >= 16384;
+  if (adaptive) bandPix = std::min<uint64_t>(bandPix, (pixTotal + 7) / 8);
   // equal bands (the last one is not a sliver)
   const uint64_t nBands = (pixTotal + bandPix - 1) / bandPix;
   bandPix = (pixTotal + nBands - 1) / nBands;
+  const uint32_t calibrationPix = adaptive ? 256u : 0u;
   ctx.stage.reserve(static_cast<size_t>(npass) * bandPix * 3);
   if (npass > ctx.rays.capacity) {
     ctx.rayCarry += ctx.drainRays();
@@ -274,6 +282,13 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   ctx.sampleQueue.reserve(1);
   b.sampleQueue = ctx.sampleQueue.ptr;
   b.specState = sequential ? ctx.specState.ptr : nullptr;
+  if (sequential && !ctx.countHist.ptr) {
+    ctx.countHist.reserve(8);
+    check(hipMemsetAsync(ctx.countHist.ptr, 0, 8 * sizeof(unsigned long long), stream), "memset");
+  }
+  b.countHist = ctx.countHist.ptr;
+  ctx.wideCands.reserve(wideCandidateBytes());
+  b.wideCands = ctx.wideCands.ptr;
 
   auto timedLaunch = [&](bool trace, auto &&launch) {
     if (!ctx.statsEnabled) {
@@ -291,10 +306,12 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   };
 
   uint64_t done = 0;
-  for (uint32_t begin = 0; begin < pixTotal; begin += static_cast<uint32_t>(bandPix)) {
+  for (uint32_t begin = 0; begin < pixTotal;) {
     t.pixBegin = begin;
     t.pixCount = static_cast<uint32_t>(std::min<uint64_t>(bandPix, pixTotal - begin));
-    t.firstBand = begin == 0;
+    if (begin == 0 && calibrationPix) t.pixCount = std::min(t.pixCount, calibrationPix);
+    begin += t.pixCount;
+    t.firstBand = t.pixBegin == 0;
     if (sequential)
       timedLaunch(true, [&] { return launchTraceSequential(t, b, stream, &ctx.traceKernel); });
     else

@@ -55,13 +55,23 @@ struct TraceBuffers {
   uint32_t *words;           // optional [npass][npix]
   unsigned long long *rays;  // optional [npass] intersect() call counters
   unsigned long long *sampleQueue; // one word: next sample index (tracePerPixelPersistent)
-  double *specState;         // [npass][kSpecStateDoubles] parked stream ring (traceSequentialSpec)
+  double *specState;         // [npass][kSpecStateDoubles] parked stream ring (traceSequentialSpec / Wide)
+  unsigned long long *countHist; // [8]: committed sub-samples by levels reached (traceSequentialWide)
+  void *wideCands;               // wideCandidateBytes(): the candidate set of traceSequentialWide
 };
 
 // SEQUENTIAL policy: one workgroup per pass walks the band's pixels in row-major order.
 // `variant` (may be null) receives the name of the kernel variant that was launched.
 hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hipStream_t stream,
                                  const char **variant = nullptr);
+// traceSequentialWide (ptw_wide.hip): the SEQUENTIAL policy for small scenes with many speculative
+// candidates per round.  Needs b.countHist (zeroed once) and b.wideCands (wideCandidateBytes()):
+// before the trace kernel a one-lane kernel builds the candidate set from the histogram of
+// per-sub-sample draw counts the previous launch left in countHist.
+bool wideKernelApplies(const TraceParams &p);
+size_t wideCandidateBytes();
+hipError_t launchTraceSequentialWide(const TraceParams &p, const TraceBuffers &b, hipStream_t stream,
+                                     const char **variant);
 // PERPIXEL policy: one lane per (pass, pixel) sample.
 hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipStream_t stream,
                                const char **variant = nullptr);

@@ -34,8 +34,7 @@
 //
 //  intersectBatchKernel, rngKatKernel   known-answer entry points (ptw_context_intersect /
 //      ptw_context_rng_doubles).
-#include "ptw_device.h"
-#include "ptw_kernels.h"
+#include "ptw_trace_common.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -59,74 +58,6 @@ namespace ptw {
 using namespace ptwd;
 
 namespace {
-
-constexpr uint32_t kMiss = 0xffffffffu;
-
-struct HitKey {
-  double t;     // distance along the ray (+inf on a miss)
-  uint32_t idx; // combined primitive index: spheres [0, nsph), triangles nsph + k; kMiss
-  double det;   // Moller-Trumbore determinant of the winning triangle (backface test)
-};
-
-// What radiance() needs to know about the surface at a hit (Scene.cpp:135-152).
-struct Surface {
-  d3 pos;
-  d3 normal;
-  Basis basis;
-  double reflectivity;    // resolved value (eager paths)
-  d3 emission;
-  d3 diffuse;
-  double coneAngle;
-  // inputs of Norm3::reflectance for paths that resolve the lobe lazily
-  double matReflectivity; // MaterialSpec::reflectivity (< 0 => Fresnel-ish)
-  double iorFrom, iorTo, iorRatio;
-};
-
-__device__ __forceinline__ double resolveReflectivity(const Surface &s, d3 dirIn) {
-  return s.matReflectivity < 0 ? reflectance(s.normal, dirIn, s.iorFrom, s.iorTo, s.iorRatio)
-                               : s.matReflectivity;
-}
-
-__device__ __forceinline__ d3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
-
-// One Moller-Trumbore test, Scene.cpp:62-98, against a triangle given as v0, e1, e2.
-// Updates (bestT, bestIdx, bestDet) when this triangle is a strictly nearer acceptable hit.
-__device__ __forceinline__ void testTriangle(d3 o, d3 d, d3 v0, d3 e1, d3 e2, uint32_t idx,
-                                             double &bestT, uint32_t &bestIdx, double &bestDet) {
-  const d3 pVec = cross(d, e2);
-  const double det = dot(e1, pVec);
-  if (__builtin_fabs(det) < kEpsilon) return;
-  const double invDet = rcp(det);
-  const d3 tVec = o - v0;
-  const double u = dot(tVec, pVec) * invDet;
-  const d3 qVec = cross(tVec, e1);
-  const double v = dot(d, qVec) * invDet;
-  if ((u < 0.0) | (u > 1.0) | (v < 0.0) | (u + v > 1)) return;
-  const double t = dot(e2, qVec) * invDet;
-  if (t > kEpsilon && t < bestT) {
-    bestT = t;
-    bestIdx = idx;
-    bestDet = det;
-  }
-}
-
-// One sphere test, Scene.cpp:17-35.
-__device__ __forceinline__ void testSphere(d3 o, d3 d, d3 centre, double radiusSquared,
-                                           uint32_t idx, double &bestT, uint32_t &bestIdx) {
-  const d3 op = centre - o;
-  const double b = dot(op, d);
-  double determinant = b * b - dot(op, op) + radiusSquared;
-  if (determinant < 0) return;
-  determinant = sqrtPos(determinant);
-  const double minusT = b - determinant;
-  const double plusT = b + determinant;
-  if (minusT < kEpsilon && plusT < kEpsilon) return;
-  const double t = minusT > kEpsilon ? minusT : plusT;
-  if (t < bestT) {
-    bestT = t;
-    bestIdx = idx;
-  }
-}
 
 // Builds the Surface for a hit.  `uniform` callers pass a wave-uniform key so the record
 // loads become scalar loads.
@@ -169,33 +100,6 @@ __device__ __forceinline__ Surface makeSurface(const TraceParams &p, const TriSh
   s.matReflectivity = reflectivity;
   s.reflectivity = resolveReflectivity(s, d);
   return s;
-}
-
-// Camera::rayFromUnit / randomRay, src/math/Camera.h:20-37,54-60.  r0..r3 are canonical
-// draws in stream order (r2, r3 unused for a pinhole camera).
-__device__ __forceinline__ void cameraRay(const ptw_camera &c, int px, int py, double r0,
-                                          double r1, double r2, double r3, d3 &o, d3 &d) {
-  const double x0 = (px + r0) * c.reciprocal_width;
-  const double y0 = (py + r1) * c.reciprocal_height;
-  const double x = 2 * x0 - 1, y = 2 * y0 - 1;
-  const d3 ax = ld3(c.axis_x), ay = ld3(c.axis_y), az = ld3(c.axis_z), centre = ld3(c.centre);
-  const d3 xContrib = (ax * -x) * c.aspect_ratio;
-  const d3 yContrib = ay * -y;
-  const d3 zContrib = az * c.camera_plane_dist;
-  const d3 direction = normalised((xContrib + yContrib) + zContrib);
-  if (c.aperture_radius == 0) {
-    o = centre;
-    d = direction;
-    return;
-  }
-  const d3 focalPoint = centre + direction * c.focal_distance;
-  const double angle = r2 * (2 * kPi - 0) + 0;      // uniform_real_distribution(0, 2*pi)
-  const double radius = r3 * (c.aperture_radius - 0) + 0;
-  double sn, cs;
-  sinCos<true>(angle, sn, cs); // r2 in [0, 1)
-  const d3 origin = (centre + (ax * cs) * radius) + (ay * sn) * radius;
-  o = origin;
-  d = normalised(focalPoint - origin); // Ray::fromTwoPoints, Ray.h:12-15
 }
 
 // -----------------------------------------------------------------------------------------
@@ -358,36 +262,6 @@ __device__ __forceinline__ void fillHemiTable(SeqShared *sh, int lane) {
   }
 }
 
-// SPEC (traceSequentialSpec): the generator output lives in a two-block ring in LDS, each block
-// with a few entries of overlap copied from its successor, so a group of consecutive draws never
-// straddles a regeneration and this context never regenerates: it only reads at (ringOff, pos).
-constexpr unsigned kRingStride = 16384;     // bytes between the two ring slots (XOR toggles)
-constexpr unsigned kRingHemiOff = 2560;     // hemi table inside a slot, after 316 canon doubles
-constexpr int kRingCanonDoubles = 316;      // 312 + 4 entries of the next block
-
-// The twist of all 624 state words by one wave (see the comment above).
-__device__ __forceinline__ void mtTwistWave(uint32_t *x, int lane) {
-  waveSync();
-  for (int base = 0; base < 227; base += 64) { // k in [0, 227): far = old x[k + 397]
-    const int k = base + lane;
-    uint32_t nv = 0;
-    if (k < 227) nv = mtTwist(x[k], x[k + 1], x[k + 397]);
-    waveSync();
-    if (k < 227) x[k] = nv;
-    waveSync();
-  }
-  for (int base = 227; base < 623; base += 64) { // k in [227, 623): far = new x[k - 227]
-    const int k = base + lane;
-    uint32_t nv = 0;
-    if (k < 623) nv = mtTwist(x[k], x[k + 1], x[k - 227]);
-    waveSync();
-    if (k < 623) x[k] = nv;
-    waveSync();
-  }
-  if (lane == 0) x[623] = mtTwist(x[623], x[0], x[396]);
-  waveSync();
-}
-
 __device__ __noinline__ void mtRegenerateWave(SeqShared *sh, int lane) {
   uint32_t *x = sh->mt;
   mtTwistWave(x, lane);
@@ -395,37 +269,6 @@ __device__ __noinline__ void mtRegenerateWave(SeqShared *sh, int lane) {
     sh->canon[i] = canonicalFromWords(mtTemper(x[2 * i]), mtTemper(x[2 * i + 1]));
   waveSync();
   fillHemiTable(sh, lane);
-  waveSync();
-}
-
-// One entry of the draw-derived hemisphere table (see SeqShared::hemi).
-__device__ __forceinline__ void hemiEntry(double u, double v, double *out) {
-  const double theta = (2 * kPi) * u;
-  const double radius = sqrtPos(v);
-  double sn, cs;
-  sinCos<true>(theta, sn, cs);
-  out[0] = cs * radius;
-  out[1] = sn * radius;
-  out[2] = sqrtPos(1 - v);
-}
-
-// SPEC ring: generates the next block of the stream into the slot at `slotOff` (one wave).  The
-// first entries of the new block are also the overlap of the block in the other slot, whose last
-// hemi entry becomes computable with them.
-__device__ __noinline__ void specGenerateBlock(uint32_t *x, char *ring, unsigned slotOff, int lane) {
-  mtTwistWave(x, lane);
-  double *canon = reinterpret_cast<double *>(ring + slotOff);
-  double *hemi = reinterpret_cast<double *>(ring + slotOff + kRingHemiOff);
-  double *otherCanon = reinterpret_cast<double *>(ring + (slotOff ^ kRingStride));
-  double *otherHemi = reinterpret_cast<double *>(ring + (slotOff ^ kRingStride) + kRingHemiOff);
-  for (int i = lane; i < kMtDoubles; i += 64)
-    canon[i] = canonicalFromWords(mtTemper(x[2 * i]), mtTemper(x[2 * i + 1]));
-  waveSync();
-  if (lane < kRingCanonDoubles - kMtDoubles) otherCanon[kMtDoubles + lane] = canon[lane];
-  waveSync();
-  for (int q = lane; q + 1 < kMtDoubles; q += 64) hemiEntry(canon[q], canon[q + 1], hemi + 3 * q);
-  if (lane == 0)
-    hemiEntry(otherCanon[kMtDoubles - 1], otherCanon[kMtDoubles], otherHemi + 3 * (kMtDoubles - 1));
   waveSync();
 }
 
@@ -1266,9 +1109,6 @@ __host__ __device__ inline size_t specLdsBytes(uint32_t ntri, uint32_t nmat, uin
   const size_t floor = 84 * 1024;
   return n < floor ? floor : n;
 }
-
-// Commands of the tracing waves to the generator wave (one word per barrier parity).
-constexpr uint32_t kGenNone = 0, kGenSlot0 = 1, kGenSlot1 = 2, kGenExit = 3;
 
 __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
     const TraceParams p, const double *__restrict__ triGeom, const SphereRec *__restrict__ spheres,
@@ -2260,8 +2100,14 @@ hipError_t dispatchSequential(const TraceParams &p, const TraceBuffers &b, hipSt
       cus = 256;
     const bool forced = specEnv && specEnv[0] == '2'; // PTW_SEQ_SPEC=2: whatever the pass count
     if (reg && !(specEnv && specEnv[0] == '0') && b.specState &&
-        (forced || p.npass <= static_cast<uint32_t>(cus)))
+        (forced || p.npass <= static_cast<uint32_t>(cus))) {
+      // ... with 32 candidates per round, 8 lanes each, where that kernel applies (PTW_SEQ_WIDE=0: the
+      // four-wave form)
+      static const char *wideEnv = std::getenv("PTW_SEQ_WIDE");
+      if (!(wideEnv && wideEnv[0] == '0') && b.countHist && b.wideCands && wideKernelApplies(p))
+        return launchTraceSequentialWide(p, b, stream, &tlsVariant);
       return launchSeqSpec(p, b, stream);
+    }
     if (reg) return launchSeq<1, 1, true, true>(p, b, stream);
     return launchSeqAuto<1, 1>(p, b, stream);
   }

@@ -41,3 +41,26 @@ def simulate(N):
 for N in (1, 2, 4, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 496):
     r, a = simulate(N)
     print(f"N={N:4d} rounds/pixel={r:6.2f} commits/round={a:5.2f}")
+
+# ---- what the ranked list looks like, and how much locality (per image row) would add ----
+if len(sys.argv) > 2:
+    N = int(sys.argv[2])
+    cs = ranked(N)
+    print("top", N, [(m, D) for _, m, D in cs])
+    # per-row adaptive ranking: distribution from the previous row's counts
+    W = int(np.sqrt(len(c)))
+    rows = sub.reshape(-1, W, 16) if hitmask.all() else None
+    if rows is not None:
+        rounds = commits = 0
+        for y in range(1, rows.shape[0]):
+            p = np.bincount(rows[y - 1].ravel(), minlength=6)[:6] / rows[y - 1].size
+            S = set((m, D) for _, m, D in ranked(N))
+            for row in rows[y]:
+                j = 0
+                while j < 16:
+                    rounds += 1
+                    m = 0; D = 0
+                    while j + m < 16 and (m, D) in S:
+                        D += row[j + m]; m += 1
+                    j += m; commits += m
+        print(f"per-row adaptive N={N}: rounds/pixel={rounds/((rows.shape[0]-1)*W):.2f} commits/round={commits/rounds:.2f}")

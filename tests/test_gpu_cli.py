@@ -60,18 +60,22 @@ def test_chunked_save_every_and_png_and_merge(pkg, tmp_path):
     ("cornell", []), ("single-sphere", ["--max-depth", "3"]), ("cornell", ["--first-bounce-u", "3", "--first-bounce-v", "5"]),
 ])
 def test_sequential_kernel_variants_write_identical_bytes(pkg, tmp_path, scene, extra):
-    """The speculative four-wave kernel, the single-wave register-stack kernel and the plain
-    single-wave kernel are three schedules of one computation: same .raw bytes.  A tiny staging
-    budget makes every pass park and resume its stream dozens of times."""
+    """The wide speculative kernel (8 or 16 lanes per candidate, full or short candidate list), the
+    speculative four-wave kernel, the single-wave register-stack kernel and the plain single-wave
+    kernel are schedules of one computation: same .raw bytes.  A tiny staging budget makes every
+    pass park and resume its stream dozens of times."""
     from conftest import ROOT
     args = ["-w", "40", "-h", "28", "--spp", "5", "--seed", "11", "--scene", scene, "--raw", "--save-every", "0"] + extra
-    variants = {"spec": {}, "reg": {"PTW_SEQ_SPEC": "0"}, "plain": {"PTW_SEQ_SPEC": "0", "PTW_SEQ_REG": "0"},
-                "spec_bands": {"PTW_STAGE_BUDGET_KB": "12"}}
+    variants = {"wide8": {"PTW_WIDE_G": "8"}, "wide16": {"PTW_WIDE_G": "16"}, "wide8_few": {"PTW_WIDE_CANDIDATES": "5"},
+                "spec": {"PTW_SEQ_WIDE": "0"}, "reg": {"PTW_SEQ_SPEC": "0"},
+                "plain": {"PTW_SEQ_SPEC": "0", "PTW_SEQ_REG": "0"},
+                "wide_bands": {"PTW_STAGE_BUDGET_KB": "12"}, "spec_bands": {"PTW_SEQ_WIDE": "0", "PTW_STAGE_BUDGET_KB": "12"}}
     blobs = {}
     for name, env in variants.items():
         run_cli(pkg, args + [str(tmp_path / f"{name}.raw")], ROOT, env=env)
         blobs[name] = (tmp_path / f"{name}.raw").read_bytes()
-    assert blobs["spec"] == blobs["reg"] == blobs["plain"] == blobs["spec_bands"]
+    for name in variants:
+        assert blobs[name] == blobs["plain"], name
 
 
 def test_gpus_flag_shards_passes_over_host_threads(pkg, tmp_path):
