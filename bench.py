@@ -223,12 +223,17 @@ def parity_vs_reference(pkg, ob, ctx, cam, view, args, threads):
     gpu_cnt = cnt.cpu().numpy().astype(np.uint32)
 
     ref_sum = np.zeros((h, w, 3))
-    stats = {"word_mismatch": 0, "words_total": 0}
+    stats = {"word_mismatch": 0, "words_total": 0, "where": []}
 
     def on_pass(k, rad, wd):   # pass order: output += pass (ArrayOutput.cpp:48-56)
         np.add(ref_sum, rad, out=ref_sum)
         gw = words[k].cpu().numpy().astype(np.uint32)
-        stats["word_mismatch"] += int(np.count_nonzero(gw != wd))
+        bad = np.argwhere(gw != wd)
+        stats["word_mismatch"] += len(bad)
+        for y, x in bad[:4]:
+            if len(stats["where"]) < 16:
+                stats["where"].append({"pass": int(k), "x": int(x), "y": int(y), "hip_words": int(gw[y, x]),
+                                       "ref_words": int(wd[y, x])})
         stats["words_total"] += int(wd.sum(dtype=np.uint64))
 
     t0 = time.perf_counter()
@@ -245,6 +250,7 @@ def parity_vs_reference(pkg, ob, ctx, cam, view, args, threads):
         "max_abs_diff": float(np.max(np.abs(diff))),
         "pixels_bit_identical": int(identical.sum()), "pixels": int(w * h),
         "samples_word_count_differs": stats["word_mismatch"], "samples": int(w) * h * spp,
+        "word_count_differences": stats["where"],
         "counts_equal": bool(np.all(gpu_cnt == spp)),
         "mean_words_per_sample": stats["words_total"] / float(w * h * spp),
         "reference": "oracle/_ref: the reference's own src/dod/Scene.cpp + src/math + ArrayOutput compiled "
