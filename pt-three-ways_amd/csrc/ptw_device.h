@@ -129,12 +129,14 @@ __device__ __forceinline__ double reflectance(d3 n, d3 incoming, double iorFrom,
 // sin and cos of x for the arguments this path produces (theta = 2*pi*u, cone angles: all in
 // [0, 2*pi]).  Cody-Waite reduction by multiples of pi/2 in three exact-product steps, then the
 // classic minimax kernels on [-pi/4, pi/4] (the fdlibm/FreeBSD k_sin / k_cos polynomials,
-// error < 1 ulp).  Arguments outside [0, 6.5] take ocml's sincos (out of line).
+// error < 1 ulp).  Arguments outside [-6.5, 6.5] take ocml's sincos (out of line).
 __device__ __noinline__ void sincosGeneral(double x, double *s, double *c) { sincos(x, s, c); }
 
 template <bool IN_RANGE = false> // IN_RANGE: the caller guarantees 0 <= x <= 6.5
 __device__ __forceinline__ void sinCos(double x, double &sn, double &cs) {
-  if (!IN_RANGE && !(x >= 0.0 && x <= 6.5)) {
+  // |x| <= 6.5 runs the reduction below (it is exact for negative multiples of pi/2 as well: fn is
+  // then negative and every product fn * c_i stays exact); cone angles are in [-pi, pi]
+  if (!IN_RANGE && !(__builtin_fabs(x) <= 6.5)) {
     sincosGeneral(x, &sn, &cs);
     return;
   }

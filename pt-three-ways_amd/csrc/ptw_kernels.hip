@@ -1595,11 +1595,18 @@ struct PixCtx {
 };
 
 constexpr int kPixBlock = 256;
+// resident waves per SIMD the PERPIXEL kernels are compiled for (A/B: -DPTW_PIX_WAVES=n)
+#ifndef PTW_PIX_WAVES
+#define PTW_PIX_WAVES 4
+#endif
+#ifndef PTW_PIX2_WAVES
+#define PTW_PIX2_WAVES 4
+#endif
 
 // 4 waves per SIMD: the (E, T) stack is one word per level, so registers are what limits
 // residency; capping them at 128 costs a few spills outside the triangle loop and pays back in
 // latency hiding.
-__global__ __launch_bounds__(kPixBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void tracePerPixel(
+__global__ __launch_bounds__(kPixBlock) __attribute__((amdgpu_waves_per_eu(PTW_PIX_WAVES, PTW_PIX_WAVES))) void tracePerPixel(
     const TraceParams p, const double *__restrict__ triGeom,
     const TriShade *__restrict__ triShade, const SphereRec *__restrict__ spheres,
     double *__restrict__ stage, uint32_t *__restrict__ words,
@@ -1652,7 +1659,7 @@ __global__ __launch_bounds__(kPixBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
 // -----------------------------------------------------------------------------------------
 constexpr int kPix2Block = 256;
 
-__global__ __launch_bounds__(kPix2Block) __attribute__((amdgpu_waves_per_eu(4, 4))) void tracePerPixelPersistent(
+__global__ __launch_bounds__(kPix2Block) __attribute__((amdgpu_waves_per_eu(PTW_PIX2_WAVES, PTW_PIX2_WAVES))) void tracePerPixelPersistent(
     const TraceParams p, const double *__restrict__ triGeom,
     const SphereRec *__restrict__ spheres, const double *__restrict__ triCompact,
     const double *__restrict__ matTable, double *__restrict__ stage, uint32_t *__restrict__ words,
@@ -2101,10 +2108,12 @@ hipError_t dispatchSequential(const TraceParams &p, const TraceBuffers &b, hipSt
     const bool forced = specEnv && specEnv[0] == '2'; // PTW_SEQ_SPEC=2: whatever the pass count
     if (reg && !(specEnv && specEnv[0] == '0') && b.specState &&
         (forced || p.npass <= static_cast<uint32_t>(cus))) {
-      // ... with 32 candidates per round, 8 lanes each, where that kernel applies (PTW_SEQ_WIDE=0: the
-      // four-wave form)
+      // PTW_SEQ_WIDE=1: the many-candidate form (ptw_wide.hip: 64 candidates per round, 8 lanes each).
+      // Measured on Cornell it does the same work per committed sub-sample as the four-wave form -
+      // what it saves per candidate it spends on candidates that are not needed - and loses on
+      // waiting (profiles/README.md, round 2), so it is not the default.
       static const char *wideEnv = std::getenv("PTW_SEQ_WIDE");
-      if (!(wideEnv && wideEnv[0] == '0') && b.countHist && b.wideCands && wideKernelApplies(p))
+      if (wideEnv && wideEnv[0] == '1' && b.countHist && b.wideCands && wideKernelApplies(p))
         return launchTraceSequentialWide(p, b, stream, &tlsVariant);
       return launchSeqSpec(p, b, stream);
     }

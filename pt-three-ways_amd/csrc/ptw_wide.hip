@@ -689,24 +689,31 @@ __global__ __launch_bounds__(kWideBlock) void traceSequentialWide(
         // ---- commit: walk the chain of candidates that started where their predecessor stopped
         //      (identical in every wave): candidate 0 is the frontier itself; candidate c's
         //      successor for the count it consumed comes from the table of the candidate set ----
+        // Lane c prepares, in parallel, what the walk needs to know about candidate c: its draw
+        // count, its rays, and the candidate that continues it (63: none in the set).
         const WideResult *res = reinterpret_cast<const WideResult *>(wideLds + resBase);
         const int metaV = lane < nCand ? res[lane].meta : 0;
+        int packV;
+        {
+          const int cnt = metaV & 0xff;
+          const int levels = (cnt * 11) >> 5; // cnt / 3 for cnt <= 27
+          unsigned next = levels >= 1 && levels <= 5 ? (succV >> (6 * (levels - 1))) & 63u : 63u;
+          packV = static_cast<int>(next | (static_cast<unsigned>(metaV & 0xff) << 8) |
+                                   (static_cast<unsigned>(metaV >> 16) << 16));
+        }
         int m = 0, D = 0;
+        unsigned raysRound = 0;
         unsigned long long chain = 0; // committed candidate indices, 6 bits each (at most 10 are kept)
         for (int c = 0; c != 63 && j + m < nSub;) {
-          const int meta = __builtin_amdgcn_readlane(metaV, c);
-          const unsigned row = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(succV), c));
-          const int cnt = meta & 0xff;
-          raysTotal += static_cast<unsigned>(meta >> 16);
-          const int levels = cnt / 3 < 5 ? cnt / 3 : 5;
-          pixHist += 1u << (6 * (levels - 1));
+          const unsigned wd = static_cast<unsigned>(__builtin_amdgcn_readlane(packV, c));
           chain |= static_cast<unsigned long long>(c) << (6 * m);
-          D += cnt;
+          D += static_cast<int>((wd >> 8) & 0xffu);
+          raysRound += wd >> 16;
           ++m;
-          c = m < 10 ? static_cast<int>((row >> (6 * (levels - 1))) & 63u) : 63;
-          if (cnt != 3 * levels) c = 63; // (a count beyond the table's reach: stop here)
+          c = m < 10 ? static_cast<int>(wd & 63u) : 63;
         }
-        if (wave == 0) { // only the wave that stores the sample needs the radiance
+        raysTotal += raysRound;
+        if (wave == 0) { // only the wave that stores the sample needs the radiance (and the statistics)
           const d3 myL = lane < nCand ? mk(res[lane].L[0], res[lane].L[1], res[lane].L[2]) : mk(0, 0, 0);
           const d3 fe = ldsD3(fs + 8 * kFsEmission), fd = ldsD3(fs + 8 * kFsDiffuse);
           for (int q = 0; q < m; ++q) {
@@ -714,6 +721,8 @@ __global__ __launch_bounds__(kWideBlock) void traceSequentialWide(
             const int meta = __builtin_amdgcn_readlane(metaV, src);
             const d3 ch = mk(readLane(myL.x, src), readLane(myL.y, src), readLane(myL.z, src));
             result = result + ((meta & 0x100) ? fe + ch : fe + fd * ch);
+            const int levels = ((meta & 0xff) * 11) >> 5;
+            pixHist += 1u << (6 * ((levels < 5 ? levels : 5) - 1));
           }
         }
         j += m;

@@ -66,10 +66,11 @@ def test_sequential_kernel_variants_write_identical_bytes(pkg, tmp_path, scene, 
     pass park and resume its stream dozens of times."""
     from conftest import ROOT
     args = ["-w", "40", "-h", "28", "--spp", "5", "--seed", "11", "--scene", scene, "--raw", "--save-every", "0"] + extra
-    variants = {"wide8": {"PTW_WIDE_G": "8"}, "wide16": {"PTW_WIDE_G": "16"}, "wide8_few": {"PTW_WIDE_CANDIDATES": "5"},
-                "spec": {"PTW_SEQ_WIDE": "0"}, "reg": {"PTW_SEQ_SPEC": "0"},
-                "plain": {"PTW_SEQ_SPEC": "0", "PTW_SEQ_REG": "0"},
-                "wide_bands": {"PTW_STAGE_BUDGET_KB": "12"}, "spec_bands": {"PTW_SEQ_WIDE": "0", "PTW_STAGE_BUDGET_KB": "12"}}
+    variants = {"spec": {}, "reg": {"PTW_SEQ_SPEC": "0"}, "plain": {"PTW_SEQ_SPEC": "0", "PTW_SEQ_REG": "0"},
+                "spec_bands": {"PTW_STAGE_BUDGET_KB": "12"},
+                "wide8": {"PTW_SEQ_WIDE": "1", "PTW_WIDE_G": "8"}, "wide16": {"PTW_SEQ_WIDE": "1", "PTW_WIDE_G": "16"},
+                "wide8_few": {"PTW_SEQ_WIDE": "1", "PTW_WIDE_CANDIDATES": "5"},
+                "wide_bands": {"PTW_SEQ_WIDE": "1", "PTW_STAGE_BUDGET_KB": "12"}}
     blobs = {}
     for name, env in variants.items():
         run_cli(pkg, args + [str(tmp_path / f"{name}.raw")], ROOT, env=env)
