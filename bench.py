@@ -77,6 +77,12 @@ def parse_args():
                     help="skip the full-frame comparison with the reference (rmse_vs_ref)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the extra measurement of the other RNG policy")
+    ap.add_argument("--accel", choices=["none", "bvh"], default="none",
+                    help="bvh: the SEPARATE accelerated mode (perpixel policy; same image, culled tests) - never "
+                         "the headline configuration")
+    ap.add_argument("--rows", default="",
+                    help="BEGIN:END - PERPIXEL only: time a sub-run of the frame (image rows [BEGIN, END) of the "
+                         "full-size frame); the workload string says so")
     ap.add_argument("--cpu-threads", type=int, default=6)
     ap.add_argument("--cpu-frame", type=int, default=0,
                     help="edge of the square frame of the CPU legs (0: per scene, cornell 1024)")
@@ -129,6 +135,15 @@ class Shard:
             self.total_spp = args.spp
             self.scaling = "strong" if args.scaling == "strong" else "weak"
             self.parallelism = "single GPU"
+        self.rows = args.height
+        if args.accel == "bvh":
+            assert self.policy == pkg.RNG_PERPIXEL, "--accel bvh needs --policy perpixel"
+            extra = dict(extra, accel=pkg.ACCEL_BVH)
+        if args.rows:
+            assert self.policy == pkg.RNG_PERPIXEL and world == 1, "--rows needs --policy perpixel on one GPU"
+            r0, r1 = (int(v) for v in args.rows.split(":"))
+            extra = dict(extra, row_begin=r0, row_end=r1)
+            self.rows = r1 - r0
         self.params = pkg.default_params(width=args.width, height=args.height, samples_per_pixel=spp,
                                          seed=args.seed, first_pass=first_pass, rng_policy=self.policy,
                                          device=local_rank, **extra)
@@ -325,7 +340,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    samples_per_step = w * h * shard.total_spp
+    samples_per_step = w * shard.rows * shard.total_spp
     total_samples = samples_per_step * args.steps
     value = total_samples / elapsed / 1e6
 
@@ -373,10 +388,13 @@ def main():
             "data": "bundled scene (scenes/CornellBox-Original.obj + reference sphere), seed 1",
             "config": {
                 "workload": f"{args.scene} {w}x{h} @ {shard.total_spp} spp, maxDepth 5, 4x4 first bounce, "
-                            f"rng_policy={args.policy}",
+                            f"rng_policy={args.policy}"
+                            + (f"; TIMED SUB-RUN: image rows [{args.rows.replace(':', ', ')}) of the {w}x{h} frame "
+                               f"({shard.rows}/{h} of its samples)" if args.rows else ""),
                 "scene": args.scene, "triangles": ntri, "spheres": nsph, "width": w, "height": h,
                 "total_spp": shard.total_spp, "spp_this_rank": int(shard.params.samples_per_pixel),
                 "rng_policy": args.policy, "parallelism": shard.parallelism,
+                "accel": args.accel,
             },
             "end_to_end_ms_per_step": elapsed / args.steps * 1e3 + scene_upload_ms + h2d_ms + d2h_ms,
             "end_to_end_note": f"ms_per_step + scene upload incl. per-primitive precompute ({scene_upload_ms:.1f} ms) "
@@ -391,7 +409,10 @@ def main():
                 "algorithmic_flop_per_launch": rays_per_launch * flop_per_ray,
                 "rays_per_sample": stats.rays / max(1, stats.samples),
                 "note": "branchy scalar fp64, no MFMA: the binding roof is the fp64 vector ALU "
-                        "(SURVEY.md 8d). algorithmic flop = intersect() calls x (ntri*45 + nsph*19)",
+                        "(SURVEY.md 8d). algorithmic flop = intersect() calls x (ntri*45 + nsph*19)"
+                        + ("; ACCELERATED MODE: `achieved` prices every ray at the brute-force test count the "
+                           "reference would do - an EFFECTIVE rate, not arithmetic performed (the BVH skips most "
+                           "tests); separate from and not comparable with the headline" if args.accel != "none" else ""),
             },
             "roofline_hbm": {
                 "bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -404,7 +425,7 @@ def main():
         }
 
     # -- the other RNG policy, same workload, same run (N = 1 only) ---------------------------
-    if world == 1 and not args.no_secondary and policy == pkg.RNG_SEQUENTIAL:
+    if world == 1 and not args.no_secondary and policy == pkg.RNG_SEQUENTIAL and not args.rows:
         p2 = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=args.seed,
                                 rng_policy=pkg.RNG_PERPIXEL)
         rgb2 = torch.zeros_like(final[0])

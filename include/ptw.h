@@ -51,6 +51,15 @@ typedef enum ptw_status {
  *               reference (same estimator, different random numbers). */
 typedef enum ptw_rng_policy { PTW_RNG_SEQUENTIAL = 0, PTW_RNG_PERPIXEL = 1 } ptw_rng_policy;
 
+/* How Scene::intersect finds the nearest hit.
+ *  NONE — the reference's algorithm: every ray tests every primitive (README.md:5-6,
+ *         src/dod/Scene.cpp:13-113).  The default, and what every headline number is measured on.
+ *  BVH  — a SEPARATE, separately reported mode: triangles a ray cannot hit are culled by a
+ *         bounding-volume hierarchy and the same Moller-Trumbore arithmetic runs on the rest, so
+ *         every sample is bit-identical to the NONE result while the work (tests per ray) is not
+ *         the reference's.  PTW_RNG_PERPIXEL only. */
+typedef enum ptw_accel { PTW_ACCEL_NONE = 0, PTW_ACCEL_BVH = 1 } ptw_accel;
+
 /* MaterialSpec, src/util/MaterialSpec.h:7-12 (same field order, 72 bytes). */
 typedef struct ptw_material {
   double emission[3];
@@ -111,7 +120,7 @@ typedef struct ptw_render_params {
   int32_t device;                /* HIP device ordinal for ptw_render()                     */
   int32_t row_stride;
   int32_t row_phase;
-  int32_t reserved[1];
+  int32_t accel;                 /* ptw_accel; default PTW_ACCEL_NONE                       */
 } ptw_render_params;
 
 /* Progress callback, the analogue of `updateFunc(output)` (src/dod/Scene.cpp:245) and of

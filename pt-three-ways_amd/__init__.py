@@ -25,6 +25,8 @@ SCENES_DIR = REPO_ROOT / "scenes"
 
 RNG_SEQUENTIAL = 0
 RNG_PERPIXEL = 1
+ACCEL_NONE = 0
+ACCEL_BVH = 1
 
 STATUS_NAMES = {
     0: "PTW_OK", 1: "PTW_ERR_INVALID", 2: "PTW_ERR_NO_DEVICE", 3: "PTW_ERR_HIP", 4: "PTW_ERR_IO",
@@ -97,7 +99,7 @@ class RenderParams(C.Structure):
                 ("first_bounce_u", C.c_int32), ("first_bounce_v", C.c_int32),
                 ("seed", C.c_int32), ("first_pass", C.c_int32), ("rng_policy", C.c_int32),
                 ("row_begin", C.c_int32), ("row_end", C.c_int32), ("device", C.c_int32),
-                ("row_stride", C.c_int32), ("row_phase", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("row_stride", C.c_int32), ("row_phase", C.c_int32), ("accel", C.c_int32)]
 
 
 class KernelStats(C.Structure):

@@ -5,6 +5,7 @@
 #include "capi_common.h"
 #include "ptw_kernels.h"
 
+#include "../host/bvh.h"
 #include "../host/precompute.h"
 
 #include <algorithm>
@@ -70,6 +71,10 @@ struct ptw_context {
   DeviceArray<TriShade> triShade;
   DeviceArray<SphereRec> spheres;
   DeviceArray<double> triCompact, matTable;
+  // accelerated mode (PTW_ACCEL_BVH): built with the scene
+  DeviceArray<BvhNode> bvhNodes;
+  DeviceArray<double> bvhLeafGeom;
+  DeviceArray<uint32_t> bvhLeafIndex;
   DeviceArray<double> specState; // parked stream rings of traceSequentialSpec
   uint32_t nmat = 0;
   DeviceArray<uint32_t> mtState, mtPos;
@@ -154,6 +159,11 @@ void validate(const ptw_render_params &p) {
   if (p.row_stride < 0 || p.row_phase < 0 || (p.row_stride > 1 && p.row_phase >= p.row_stride) ||
       (p.row_stride <= 1 && p.row_phase != 0))
     throw std::invalid_argument("bad row_stride / row_phase");
+  if (p.accel != PTW_ACCEL_NONE && p.accel != PTW_ACCEL_BVH) throw std::invalid_argument("unknown accel mode");
+  if (p.accel != PTW_ACCEL_NONE && p.rng_policy != PTW_RNG_PERPIXEL)
+    throw DeviceError(PTW_ERR_UNSUPPORTED,
+                      "the accelerated mode needs PTW_RNG_PERPIXEL (the SEQUENTIAL kernels search the "
+                      "scene cooperatively, a lane per primitive)");
   if (p.rng_policy == PTW_RNG_SEQUENTIAL && (p.row_begin != 0 || p.row_end != 0 || p.row_stride > 1))
     throw DeviceError(PTW_ERR_UNSUPPORTED,
                       "a row window needs PTW_RNG_PERPIXEL: under PTW_RNG_SEQUENTIAL the pixels of a "
@@ -205,6 +215,7 @@ TraceParams makeTraceParams(const ptw_context &ctx, const ptw_camera &cam,
   t.npass = static_cast<uint32_t>(p.samples_per_pixel);
   t.rowFirst = 0;
   t.rowStride = 1;
+  t.accel = p.accel;
   return t;
 }
 
@@ -287,6 +298,9 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
     ctx.countHist.reserve(8);
     check(hipMemsetAsync(ctx.countHist.ptr, 0, 8 * sizeof(unsigned long long), stream), "memset");
   }
+  b.bvhNodes = ctx.bvhNodes.ptr;
+  b.bvhLeafGeom = ctx.bvhLeafGeom.ptr;
+  b.bvhLeafIndex = ctx.bvhLeafIndex.ptr;
   b.countHist = ctx.countHist.ptr;
   ctx.wideCands.reserve(wideCandidateBytes());
   b.wideCands = ctx.wideCands.ptr;
@@ -374,6 +388,10 @@ int ptw_context_set_scene(ptw_context *ctx, const ptw_scene_view *scene) {
   ctx->triCompact.upload(data.triCompact.data(), data.triCompact.size(), nullptr);
   ctx->matTable.upload(data.matTable.data(), data.matTable.size(), nullptr);
   ctx->nmat = scene->num_materials;
+  const Bvh bvh = buildBvh(data.triGeom.data(), scene->num_triangles);
+  ctx->bvhNodes.upload(bvh.nodes.data(), bvh.nodes.size(), nullptr);
+  ctx->bvhLeafGeom.upload(bvh.leafGeom.data(), bvh.leafGeom.size(), nullptr);
+  ctx->bvhLeafIndex.upload(bvh.leafIndex.data(), bvh.leafIndex.size(), nullptr);
   check(hipStreamSynchronize(nullptr), "scene upload");
   ctx->ntri = scene->num_triangles;
   ctx->nsph = scene->num_spheres;

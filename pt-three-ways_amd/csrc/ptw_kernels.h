@@ -32,7 +32,7 @@ struct TraceParams {
   int32_t firstBand;     // this launch starts the passes' streams (first band of a render)
   int32_t rowFirst;      // image row of local row 0
   int32_t rowStride;     // image rows between consecutive local rows (>= 1)
-  int32_t padB;
+  int32_t accel;         // ptw_accel: PERPIXEL only
 };
 
 // Global (row-major, full-frame) index of local pixel l.
@@ -58,6 +58,10 @@ struct TraceBuffers {
   double *specState;         // [npass][kSpecStateDoubles] parked stream ring (traceSequentialSpec / Wide)
   unsigned long long *countHist; // [8]: committed sub-samples by levels reached (traceSequentialWide)
   void *wideCands;               // wideCandidateBytes(): the candidate set of traceSequentialWide
+  // accelerated mode (host/bvh.h)
+  const void *bvhNodes;
+  const double *bvhLeafGeom;
+  const uint32_t *bvhLeafIndex;
 };
 
 // SEQUENTIAL policy: one workgroup per pass walks the band's pixels in row-major order.

@@ -1477,11 +1477,25 @@ __device__ __forceinline__ TriRegs loadTriUniform(const double *__restrict__ tri
   return t;
 }
 
-struct PixCtx {
+// Device view of the BVH of the accelerated mode (host/bvh.h).
+struct BvhNodeDev {
+  double lo[2][3], hi[2][3];
+  int32_t child[2];
+  int32_t count[2];
+};
+constexpr int kBvhStack = 32;
+
+template <bool BVH>
+struct PixCtxT {
   const TraceParams *p;
   const double *triGeom;
   const TriShade *triShade;
   const SphereRec *spheres;
+  // BVH mode only
+  const BvhNodeDev *bvhNodes;
+  const double *bvhLeafGeom;
+  const uint32_t *bvhLeafIndex;
+  int32_t *bvhStack; // this lane's slice of the block's LDS traversal stack, stride = blockDim.x
   __device__ __forceinline__ Surface surfaceAt(const HitKey &k, d3 o, d3 d, bool = true) const {
     return makeSurface(*p, triShade, spheres, k, o, d);
   }
@@ -1546,6 +1560,79 @@ struct PixCtx {
     return radianceChain(*this, tp, ts, sp, o, d);
   }
 
+  // One Moller-Trumbore test that keeps the lexicographic minimum of (t, combined index): the
+  // BVH visits triangles in its own order, and the reference's scan (strict `<` in insertion
+  // order, spheres first) resolves exact ties towards the lowest index.
+  __device__ __forceinline__ static void testTriangleLex(d3 o, d3 d, d3 v0, d3 e1, d3 e2, uint32_t idx,
+                                                         HitKey &key) {
+    const d3 pVec = cross(d, e2);
+    const double det = dot(e1, pVec);
+    if (__builtin_fabs(det) < kEpsilon) return;
+    const double invDet = rcp(det);
+    const d3 tVec = o - v0;
+    const double u = dot(tVec, pVec) * invDet;
+    const d3 qVec = cross(tVec, e1);
+    const double v = dot(d, qVec) * invDet;
+    if ((u < 0.0) | (u > 1.0) | (v < 0.0) | (u + v > 1)) return;
+    const double t = dot(e2, qVec) * invDet;
+    if (t > kEpsilon && (t < key.t || (t == key.t && idx < key.idx))) {
+      key.t = t;
+      key.idx = idx;
+      key.det = det;
+    }
+  }
+
+  // Scene::intersect with triangles culled by the BVH: the same tests on fewer triangles, the same
+  // nearest hit (see host/bvh.h for why nothing that could win is skipped).
+  __device__ __forceinline__ void intersectBvh(d3 o, d3 d, HitKey &key) {
+    const uint32_t nsph = p->nsph;
+    const double ix = 1.0 / d.x, iy = 1.0 / d.y, iz = 1.0 / d.z; // IEEE: +-inf for a zero component
+    const int stride = blockDim.x;
+    int sp = 0;
+    bvhStack[0] = 0;
+    sp = 1;
+    while (sp > 0) {
+      const BvhNodeDev &n = bvhNodes[bvhStack[--sp * stride]];
+      double entry[2];
+      bool hit[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        // slab test; fmin / fmax drop the NaN of 0 * inf (origin on a slab plane of a flat axis)
+        const double ax = (n.lo[c][0] - o.x) * ix, bx = (n.hi[c][0] - o.x) * ix;
+        const double ay = (n.lo[c][1] - o.y) * iy, by = (n.hi[c][1] - o.y) * iy;
+        const double az = (n.lo[c][2] - o.z) * iz, bz = (n.hi[c][2] - o.z) * iz;
+        const double tmin = __builtin_fmax(__builtin_fmax(__builtin_fmin(ax, bx), __builtin_fmin(ay, by)),
+                                           __builtin_fmin(az, bz));
+        const double tmax = __builtin_fmin(__builtin_fmin(__builtin_fmax(ax, bx), __builtin_fmax(ay, by)),
+                                           __builtin_fmax(az, bz));
+        entry[c] = tmin;
+        // `<=`: a box whose entry distance equals the best hit may hold an exact tie
+        hit[c] = n.count[c] >= 0 && tmin <= tmax && tmax >= 0.0 && tmin <= key.t;
+      }
+      // leaves are tested at once, inner children go on the stack (the nearer one on top)
+      int push[2], npush = 0;
+      const int first = (hit[0] && hit[1] && entry[1] < entry[0]) ? 1 : 0;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int c = k == 0 ? first : 1 - first;
+        if (!hit[c]) continue;
+        if (n.count[c] > 0) {
+          if (!(entry[c] <= key.t)) continue; // the other leaf may have shortened the ray
+          for (int i = 0; i < n.count[c]; ++i) {
+            const uint32_t e = static_cast<uint32_t>(n.child[c] + i);
+            const double *g = bvhLeafGeom + 9 * static_cast<size_t>(e);
+            testTriangleLex(o, d, ld3(g), ld3(g + 3), ld3(g + 6), nsph + bvhLeafIndex[e], key);
+          }
+        } else {
+          push[npush++] = n.child[c];
+        }
+      }
+      // nearer child last, so that it is popped first
+      for (int k = npush - 1; k >= 0; --k)
+        if (sp < kBvhStack) bvhStack[sp++ * stride] = push[k];
+    }
+  }
+
   __device__ __forceinline__ HitKey intersect(d3 o, d3 d) {
     rays++;
     HitKey key;
@@ -1554,6 +1641,10 @@ struct PixCtx {
     for (uint32_t i = 0; i < nsph; ++i) {
       const SphereRec &r = spheres[i];
       testSphere(o, d, ld3(r.centre), r.radiusSquared, i, key.t, key.idx);
+    }
+    if (BVH) {
+      if (ntri) intersectBvh(o, d, key);
+      return key;
     }
     if (ntri < 128) { // short lists: the plain loop (compiler-scheduled) is fastest
       for (uint32_t k = 0; k < ntri; ++k) {
@@ -1594,6 +1685,8 @@ struct PixCtx {
   }
 };
 
+using PixCtx = PixCtxT<false>;
+
 constexpr int kPixBlock = 256;
 // resident waves per SIMD the PERPIXEL kernels are compiled for (A/B: -DPTW_PIX_WAVES=n)
 #ifndef PTW_PIX_WAVES
@@ -1606,12 +1699,8 @@ constexpr int kPixBlock = 256;
 // 4 waves per SIMD: the (E, T) stack is one word per level, so registers are what limits
 // residency; capping them at 128 costs a few spills outside the triangle loop and pays back in
 // latency hiding.
-__global__ __launch_bounds__(kPixBlock) __attribute__((amdgpu_waves_per_eu(PTW_PIX_WAVES, PTW_PIX_WAVES))) void tracePerPixel(
-    const TraceParams p, const double *__restrict__ triGeom,
-    const TriShade *__restrict__ triShade, const SphereRec *__restrict__ spheres,
-    double *__restrict__ stage, uint32_t *__restrict__ words,
-    unsigned long long *__restrict__ rayCounters) {
-  extern __shared__ uint32_t pixStacks[]; // [maxDepth][blockDim.x]
+template <bool BVH>
+__device__ __forceinline__ void perPixelSample(const TraceParams &p, const TraceBuffers &b, uint32_t *ldsWords) {
   const uint64_t gid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
   if (gid >= total) return;
@@ -1620,14 +1709,19 @@ __global__ __launch_bounds__(kPixBlock) __attribute__((amdgpu_waves_per_eu(PTW_P
   const uint32_t i = static_cast<uint32_t>(gid % p.pixCount);
   const uint32_t pix = globalPixel(p, p.pixBegin + i);
 
-  PixCtx ctx;
+  PixCtxT<BVH> ctx;
   ctx.p = &p;
-  ctx.triGeom = triGeom;
-  ctx.triShade = triShade;
-  ctx.spheres = spheres;
+  ctx.triGeom = b.triGeom;
+  ctx.triShade = b.triShade;
+  ctx.spheres = b.spheres;
+  ctx.bvhNodes = reinterpret_cast<const BvhNodeDev *>(b.bvhNodes);
+  ctx.bvhLeafGeom = b.bvhLeafGeom;
+  ctx.bvhLeafIndex = b.bvhLeafIndex;
+  const int levels = p.maxDepth > 1 ? p.maxDepth - 1 : 1;
+  ctx.bvhStack = reinterpret_cast<int32_t *>(ldsWords + static_cast<size_t>(levels) * blockDim.x) + threadIdx.x;
   ctx.words = 0;
   ctx.rays = 0;
-  ctx.stack = pixStacks + threadIdx.x;
+  ctx.stack = ldsWords + threadIdx.x;
   ctx.rng.seed(p.passSeedBase + pass, pix);
 
   const int px = static_cast<int>(pix % static_cast<uint32_t>(p.width));
@@ -1641,11 +1735,25 @@ __global__ __launch_bounds__(kPixBlock) __attribute__((amdgpu_waves_per_eu(PTW_P
   }
   d3 o, d;
   cameraRay(p.cam, px, py, r0, r1, r2, r3, o, d);
-  const d3 L = radiance0(ctx, p, triShade, spheres, o, d);
-  double *out = stage + (static_cast<size_t>(pass) * p.pixCount + i) * 3;
+  const d3 L = radiance0(ctx, p, b.triShade, b.spheres, o, d);
+  double *out = b.stage + (static_cast<size_t>(pass) * p.pixCount + i) * 3;
   out[0] = L.x, out[1] = L.y, out[2] = L.z;
-  if (words) words[static_cast<size_t>(pass) * p.npix + pix] = ctx.words;
-  if (rayCounters) atomicAdd(&rayCounters[pass], ctx.rays);
+  if (b.words) b.words[static_cast<size_t>(pass) * p.npix + pix] = ctx.words;
+  if (b.rays) atomicAdd(&b.rays[pass], ctx.rays);
+}
+
+__global__ __launch_bounds__(kPixBlock) __attribute__((amdgpu_waves_per_eu(PTW_PIX_WAVES, PTW_PIX_WAVES))) void tracePerPixel(
+    const TraceParams p, const TraceBuffers b) {
+  extern __shared__ uint32_t pixStacks[]; // [maxDepth][blockDim.x]
+  perPixelSample<false>(p, b, pixStacks);
+}
+
+// ACCELERATED mode (ptw_render_params.accel == PTW_ACCEL_BVH): the same
+// sample, with Scene::intersect culled by a BVH - bit-identical results, different work.  Reported
+// separately, never in the headline numbers.
+__global__ __launch_bounds__(kPixBlock) void tracePerPixelBvh(const TraceParams p, const TraceBuffers b) {
+  extern __shared__ uint32_t pixStacks[]; // [maxDepth][blockDim.x] levels + [kBvhStack][blockDim.x] traversal
+  perPixelSample<true>(p, b, pixStacks);
 }
 
 // -----------------------------------------------------------------------------------------
@@ -2137,6 +2245,15 @@ hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipS
   // nearest-hit search, where the persistent kernel's lane re-use pays.  PTW_PIX_KERNEL
   // (legacy|persistent) overrides for A/B runs.
   static const char *forced = std::getenv("PTW_PIX_KERNEL");
+  if (p.accel == PTW_ACCEL_BVH) {
+    if (variant) *variant = "tracePerPixelBvh";
+    const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
+    const uint32_t blocks = static_cast<uint32_t>((total + kPixBlock - 1) / kPixBlock);
+    const int levels = p.maxDepth > 1 ? p.maxDepth - 1 : 1;
+    const size_t lds = static_cast<size_t>(levels + kBvhStack) * kPixBlock * sizeof(uint32_t);
+    hipLaunchKernelGGL(tracePerPixelBvh, dim3(blocks), dim3(kPixBlock), lds, stream, p, b);
+    return hipGetLastError();
+  }
   const bool persistent = forced ? std::string(forced) == "persistent" : p.ntri >= 128;
   if (variant) *variant = persistent ? "tracePerPixelPersistent" : "tracePerPixel";
   if (persistent) {
@@ -2161,8 +2278,7 @@ hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipS
   const uint32_t blocks = static_cast<uint32_t>((total + kPixBlock - 1) / kPixBlock);
   const int levels = p.maxDepth > 1 ? p.maxDepth - 1 : 1;
   const size_t lds = static_cast<size_t>(levels) * kPixBlock * sizeof(uint32_t);
-  hipLaunchKernelGGL(tracePerPixel, dim3(blocks), dim3(kPixBlock), lds, stream, p, b.triGeom,
-                     b.triShade, b.spheres, b.stage, b.words, b.rays);
+  hipLaunchKernelGGL(tracePerPixel, dim3(blocks), dim3(kPixBlock), lds, stream, p, b);
   return hipGetLastError();
 }
 

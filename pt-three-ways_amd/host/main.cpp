@@ -56,6 +56,8 @@ void printHelp() {
                "  --device <n>               HIP device ordinal (0)\n"
                "  --gpus <n>                 shard the passes over devices <device> .. <device>+n-1 (1)\n"
                "  --rng <policy>             sequential (reference-exact, default) | perpixel\n"
+               "  --accel <mode>             none (the reference's brute force, default) | bvh (perpixel only:\n"
+               "                             same image, triangles culled by a bounding-volume hierarchy)\n"
                "  --scenes-dir <dir>         where the .obj/.mtl files live (scenes)\n"
                "  -?, --help\n";
 }
@@ -97,6 +99,11 @@ Options parse(int argc, const char *argv[]) {
       if (p == "sequential") o.params.rng_policy = PTW_RNG_SEQUENTIAL;
       else if (p == "perpixel") o.params.rng_policy = PTW_RNG_PERPIXEL;
       else usageError("Unknown rng policy " + p);
+    } else if (a == "--accel") {
+      const std::string m = value(i, a);
+      if (m == "none") o.params.accel = PTW_ACCEL_NONE;
+      else if (m == "bvh") o.params.accel = PTW_ACCEL_BVH;
+      else usageError("Unknown accel mode " + m);
     } else if (a == "-?" || a == "--help") o.help = true;
     else if (!a.empty() && a[0] == '-' && a.size() > 1) usageError("Unrecognised token: " + a);
     else o.output = a;

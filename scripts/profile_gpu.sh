@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
-CMD="python $REPO/bench.py --width 256 --height 256 --steps 1 --no-cpu-baseline"
+CMD="python $REPO/bench.py --width 256 --height 256 --steps 1 --no-cpu-baseline --no-parity"
 # 1) kernel trace + stats
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 # 2) PMC passes (own runs, no tracing)
