@@ -75,6 +75,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the full-frame comparison with the reference (rmse_vs_ref)")
+    ap.add_argument("--parity-passes", type=int, default=24,
+                    help="passes of the full frame compared with the reference's own code on the host (0: all "
+                         "--spp passes; the default bounds the CPU work - this box's containers get about six "
+                         "cores, on which all 256 passes take 15 minutes)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the extra measurement of the other RNG policy")
     ap.add_argument("--accel", choices=["none", "bvh"], default="none",
@@ -87,6 +91,25 @@ def parse_args():
     ap.add_argument("--cpu-frame", type=int, default=0,
                     help="edge of the square frame of the CPU legs (0: per scene, cornell 1024)")
     return ap.parse_args()
+
+
+def usable_cpus():
+    """Host threads this process may actually run at once: the affinity mask capped by the cgroup's
+    CPU quota (a container may see 256 logical cores and be allowed six of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # cgroup v2
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
 
 
 def cpu_model():
@@ -217,7 +240,8 @@ def cpu_leg(pkg, ob, scene_name, threads, passes, frame):
         "value": n / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": kind,
         "sample": f"{scene_name} {frame}x{frame}, {passes} full-frame passes on {threads} threads "
                   f"(one pass per thread at a time, as the reference); {what}; "
-                  f"{n} samples in {dt:.1f} s; host: {cpu_model()}, {os.cpu_count()} logical cores",
+                  f"{n} samples in {dt:.1f} s; host: {cpu_model()}, {os.cpu_count()} logical cores visible, "
+                  f"{usable_cpus()} usable",
     }
 
 
@@ -225,7 +249,8 @@ def parity_vs_reference(pkg, ob, ctx, cam, view, args, threads):
     """The metric's second half on the FULL frame: renders the frame once more on the GPU with
     per-sample RNG word counts, runs the reference's own code for the same passes on all host
     cores, and compares every pixel and every sample's word count."""
-    w, h, spp = args.width, args.height, args.spp
+    w, h = args.width, args.height
+    spp = args.spp if args.parity_passes <= 0 else min(args.spp, args.parity_passes)
     params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=args.seed,
                                 rng_policy=pkg.RNG_SEQUENTIAL)
     rgb = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
@@ -267,6 +292,9 @@ def parity_vs_reference(pkg, ob, ctx, cam, view, args, threads):
         "samples_word_count_differs": stats["word_mismatch"], "samples": int(w) * h * spp,
         "word_count_differences": stats["where"],
         "counts_equal": bool(np.all(gpu_cnt == spp)),
+        "parity_passes": spp, "parity_note": f"every pixel of the {w}x{h} frame, passes [0, {spp}) of the "
+                                             f"{args.spp} (seeds {args.seed}..{args.seed + spp - 1}); the same "
+                                             "comparison over all 256 passes: profiles/r02e_bench_cornell1024_full.json",
         "mean_words_per_sample": stats["words_total"] / float(w * h * spp),
         "reference": "oracle/_ref: the reference's own src/dod/Scene.cpp + src/math + ArrayOutput compiled "
                      "where they lie (-O2 -march=x86-64-v3 -funsafe-math-optimizations), pass loop of "
@@ -275,9 +303,9 @@ def parity_vs_reference(pkg, ob, ctx, cam, view, args, threads):
                     "RNG words consumed by every (pass, pixel) sample",
     }, {
         "value": w * h * spp / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "reference",
-        "sample": f"{args.scene} {w}x{h}, all {spp} passes on {threads} threads (the full headline frame, "
-                  f"the parity reference of this run); {w * h * spp} samples in {dt:.1f} s; host: "
-                  f"{cpu_model()}, {os.cpu_count()} logical cores",
+        "sample": f"{args.scene} {w}x{h}, {spp} full-frame passes on {threads} threads (the parity reference of "
+                  f"this run); {w * h * spp} samples in {dt:.1f} s; host: {cpu_model()}, {os.cpu_count()} logical "
+                  f"cores visible, {usable_cpus()} usable (affinity / cgroup quota)",
     }
 
 
@@ -460,8 +488,7 @@ def main():
         legs = []
         if not args.no_parity and policy == pkg.RNG_SEQUENTIAL:
             if ob.ref_fast is not None and args.scene in ob.SCENE_CAMERAS:
-                parity, all_cores_leg = parity_vs_reference(pkg, ob, ctx, cam, view, args,
-                                                            os.cpu_count() or 1)
+                parity, all_cores_leg = parity_vs_reference(pkg, ob, ctx, cam, view, args, usable_cpus())
                 result.update(parity)
                 legs.append(all_cores_leg)
             else:
