@@ -62,42 +62,35 @@ namespace {
 
 constexpr int kWideWaves = 8;       // tracing waves: two per SIMD of the CU
 constexpr int kWideBlock = 64 * kWideWaves;
-constexpr int kWideSlots = 64;      // candidates in flight: kWideWaves x 64 / G, one per lane in the bookkeeping
-constexpr int kWideRanked = 128;    // length of the ranked candidate list (two entries per lane)
+constexpr int kWideMaxCand = 64;    // candidates per round: kWideWaves x 64 / G, one per lane in the walk
 constexpr int kWideSphereSlots = 2; // spheres per lane: up to 2 G spheres
-constexpr int kWideMaxSub = 16;     // first-bounce fan-outs up to 16 sub-samples (the usual 4 x 4)
 
 // LDS triangle record of this kernel (doubles): what a hit and a fold need, one fetch each.
 constexpr int kWtNormal = 0, kWtBasisX = 3, kWtBasisY = 6, kWtThreshold = 9, kWtDiffuse = 10,
               kWtEmission = 13, kWtMaterial = 16, kWtDoubles = 18;
 
-// The candidate set of a band (device memory, written by wideBuildCandidates): nodes (m, D) ranked
-// by the probability that the true chain reaches them with every node before it in the list.
-struct WideCandidates {
-  uint16_t node[kWideRanked]; // m << 8 | D: sub-sample frontier + m, D draws after the frontier
-  int32_t count;
-  int32_t maxD; // largest D in the list (how far ahead of the frontier a candidate starts)
+struct alignas(16) WideResult { // one per candidate and round parity, in LDS
+  double L[3]; // radiance of the sub-path below the first-bounce surface
+  int meta;    // canonical doubles consumed | lobe at the first-bounce surface << 8 | rays << 16
+  int pad;
 };
 
-// A slot's bookkeeping word: status << 28 | rays << 16 | lobe at the first bounce << 8 | draws consumed.
-constexpr unsigned kSlotFree = 0u, kSlotRunning = 1u, kSlotDone = 2u;
-constexpr unsigned kNoNode = 0xffffffffu; // slot key: sub-sample << 16 | draws since the pixel's first sub-sample
+// The candidate set of a band (device memory, written by wideBuildCandidates).
+struct WideCandidates {
+  uint16_t node[kWideMaxCand]; // candidate c = m << 8 | D: sub-sample j + m, D draws after the frontier
+  uint32_t succ[kWideMaxCand]; // 6-bit fields: the candidate that continues c when c consumed 3 (k + 1)
+                               // draws, k = 0..4 (63: not in the set)
+  int32_t count;
+  int32_t maxD; // largest D in the list (how far ahead of the frontier a round reads)
+};
 
 // ---- LDS layout (byte offsets into wideLds) ----
 constexpr unsigned kOffRing = 0;
 constexpr unsigned kOffMt = 2 * kRingStride;
-constexpr unsigned kOffSlotNode = kOffMt + kMtWords * sizeof(uint32_t);      // u32 [kWideSlots]
-constexpr unsigned kOffSlotMeta = kOffSlotNode + kWideSlots * 4;             // u32 [kWideSlots]
-constexpr unsigned kOffSlotL = (kOffSlotMeta + kWideSlots * 4 + 15) & ~15u;  // double [kWideSlots][3]
-// which slot holds (or held) node (j, S): u8 [kWideMaxSub][kPresentCols], entry = slot + 1, validated
-// against slotNode when read
-constexpr unsigned kPresentCols = 144; // S / 3 <= 15 sub-samples x 9 levels
-constexpr unsigned kOffPresent = kOffSlotL + kWideSlots * 24;
-// per-wave scratch: the nodes still wanted this step, compacted (u16 [kWideRanked] per wave)
-constexpr unsigned kOffCompact = (kOffPresent + kWideMaxSub * kPresentCols + 15) & ~15u;
+constexpr unsigned kOffResults = kOffMt + kMtWords * sizeof(uint32_t);
 // the first-bounce surface of the current pixel: every tracing wave keeps its own copy (it computes
-// the same values) so that no synchronisation is needed; candidates re-read what they need
-constexpr unsigned kFirstDoubles = 24, kOffFirst = (kOffCompact + kWideWaves * kWideRanked * 2 + 63) & ~63u;
+// the same values) so that no synchronisation is needed; rounds re-read what they need
+constexpr unsigned kFirstDoubles = 24, kOffFirst = (kOffResults + 2 * kWideMaxCand * sizeof(WideResult) + 63) & ~63u;
 constexpr unsigned kOffTables = kOffFirst + kWideWaves * kFirstDoubles * 8;
 // layout of that record (doubles)
 constexpr unsigned kFsPos = 0, kFsNormal = 3, kFsBasisX = 6, kFsBasisY = 9, kFsEmission = 12, kFsDiffuse = 15,
@@ -164,13 +157,13 @@ __device__ __forceinline__ void testTriangleSelect(d3 o, d3 d, d3 v0, d3 e1, d3 
   bestCode = take ? (code0 | (det < kEpsilon ? 1u : 0u)) : bestCode;
 }
 
-template <int G, int SLOTS, int SPH>
+template <int G, int SLOTS>
 struct WideGeom {
   // this lane's share of the scene (lane s of a group owns primitives s, s + G, s + 2 G, ...)
   double v0x[SLOTS], v0y[SLOTS], v0z[SLOTS];
   double e1x[SLOTS], e1y[SLOTS], e1z[SLOTS];
   double e2x[SLOTS], e2y[SLOTS], e2z[SLOTS];
-  double scx[SPH], scy[SPH], scz[SPH], sr2[SPH]; // SPH sphere slots: up to SPH x G spheres
+  double scx[kWideSphereSlots], scy[kWideSphereSlots], scz[kWideSphereSlots], sr2[kWideSphereSlots];
 
   __device__ __forceinline__ void load(const TraceParams &p, const double *triGeom, const SphereRec *spheres,
                                        int sub) {
@@ -185,7 +178,7 @@ struct WideGeom {
       e2x[k] = valid ? g[6] : 0.0, e2y[k] = valid ? g[7] : 0.0, e2z[k] = valid ? g[8] : 0.0;
     }
 #pragma unroll
-    for (int k = 0; k < SPH; ++k) {
+    for (int k = 0; k < kWideSphereSlots; ++k) {
       const uint32_t idx = static_cast<uint32_t>(k * G + sub);
       const bool valid = idx < p.nsph;
       const SphereRec &r = spheres[valid ? idx : 0u];
@@ -204,8 +197,8 @@ struct WideGeom {
     if (p.nsph != 0) {
       uint32_t idx = kMiss;
       testSphere(o, d, mk(scx[0], scy[0], scz[0]), sr2[0], static_cast<uint32_t>(sub), bestT, idx);
-      if (SPH > 1 && p.nsph > static_cast<uint32_t>(G))
-        testSphere(o, d, mk(scx[SPH - 1], scy[SPH - 1], scz[SPH - 1]), sr2[SPH - 1], static_cast<uint32_t>(G + sub), bestT, idx);
+      if (p.nsph > static_cast<uint32_t>(G))
+        testSphere(o, d, mk(scx[1], scy[1], scz[1]), sr2[1], static_cast<uint32_t>(G + sub), bestT, idx);
       bestCode = idx == kMiss ? kCodeMiss : idx << 1;
     }
 #pragma unroll
@@ -397,7 +390,7 @@ __device__ __noinline__ void wideGenerateBlock(unsigned slotOff) {
   ldsBarrier();
 }
 
-template <int G, int SLOTS, int SPH>
+template <int G, int SLOTS>
 __global__ __launch_bounds__(kWideBlock) void traceSequentialWide(
     const TraceParams p, const WideCandidates *__restrict__ candSet, const double *__restrict__ triGeom,
     const SphereRec *__restrict__ spheres, const double *__restrict__ triCompact,
@@ -405,22 +398,14 @@ __global__ __launch_bounds__(kWideBlock) void traceSequentialWide(
     double *__restrict__ stage, uint32_t *__restrict__ words, unsigned long long *__restrict__ rayCounters,
     unsigned long long *__restrict__ countHist) {
   constexpr int kBlock = kWideBlock;
-  constexpr int kGroups = 64 / G; // candidates (slots) per wave
-  constexpr int kSlots = kGroups * kWideWaves; // 64 (G = 8) or 32 (G = 16): lane c < kSlots keeps the books of slot c
-  static_assert(kSlots <= kWideSlots, "one bookkeeping lane per slot");
+  constexpr int kGroups = 64 / G; // candidates per wave
   char *ring = reinterpret_cast<char *>(wideLds + kOffRing);
   uint32_t *mt = reinterpret_cast<uint32_t *>(wideLds + kOffMt);
-  uint32_t *slotNode = reinterpret_cast<uint32_t *>(wideLds + kOffSlotNode);
-  uint32_t *slotMeta = reinterpret_cast<uint32_t *>(wideLds + kOffSlotMeta);
-  double *slotL = reinterpret_cast<double *>(wideLds + kOffSlotL);
-  unsigned char *present = reinterpret_cast<unsigned char *>(wideLds + kOffPresent);
 
   const int pass = blockIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int sub = lane % G;
-  const int mySlot = wave * kGroups + lane / G; // the slot this lane's group works for
-  uint16_t *compact = reinterpret_cast<uint16_t *>(wideLds + kOffCompact) + wave * kWideRanked;
 
   // ---- shading tables into LDS: spheres and materials as they are, triangles re-packed ----
   WideTables tab;
@@ -444,9 +429,8 @@ __global__ __launch_bounds__(kWideBlock) void traceSequentialWide(
       r[kWtMaterial] = c[kTriMaterialIndex];
       r[kWtMaterial + 1] = 0;
     }
-    for (uint32_t i = threadIdx.x; i < kWideMaxSub * kPresentCols; i += kBlock) present[i] = 0;
   }
-  WideGeom<G, SLOTS, SPH> geom;
+  WideGeom<G, SLOTS> geom;
   geom.load(p, triGeom, spheres, sub);
 
   // ---- the stream: resume (or start) this pass's generator ring (format of traceSequentialSpec) ----
@@ -476,7 +460,8 @@ __global__ __launch_bounds__(kWideBlock) void traceSequentialWide(
   __syncthreads();
 
   // The block after the next is generated when the frontier has crossed into the other slot: the
-  // slot it left is free then (whatever still pointed into it is behind the frontier, i.e. dead).
+  // slot it left is free then (every wave is past the round's barrier and reads the ring again
+  // only in the next round).
   auto advanceFrontier = [&](int n) { // n < kMtDoubles; uniform
     const int np = fQ + n;
     if (np >= kMtDoubles) {
@@ -489,10 +474,13 @@ __global__ __launch_bounds__(kWideBlock) void traceSequentialWide(
     }
   };
 
-  // the ranked candidate list: lane r holds entries r and 64 + r
-  const int nRanked = __builtin_amdgcn_readfirstlane(candSet->count);
-  const unsigned rk0 = lane < nRanked ? candSet->node[lane] : 0xffffu;
-  const unsigned rk1 = 64 + lane < nRanked ? candSet->node[64 + lane] : 0xffffu;
+  // this lane's candidate (the group it belongs to) and, for the walk after a round, what lane c
+  // knows about candidate c
+  const int nCand = __builtin_amdgcn_readfirstlane(candSet->count);
+  const int myCand = wave * kGroups + lane / G;
+  const unsigned myNode = myCand < nCand ? candSet->node[myCand] : 0xffffu;
+  const int myM = static_cast<int>(myNode >> 8), myD = static_cast<int>(myNode & 0xff);
+  const unsigned succV = lane < nCand ? candSet->succ[lane] : 0xffffffffu;
 
   const int maxDepth = p.maxDepth;
   const int w = p.width;
@@ -502,34 +490,21 @@ __global__ __launch_bounds__(kWideBlock) void traceSequentialWide(
   const bool fastFan = (p.uPow2 & p.vPow2) != 0;
   const int vMask = p.fbV - 1;
   const uint32_t nsph = p.nsph;
-  const int maxLevelDraws = 3 * (maxDepth > 0 ? maxDepth : 1);
   const d3 envColour = ld3(p.env);
   double *myStage = stage + static_cast<size_t>(pass) * p.pixCount * 3;
   unsigned long long raysTotal = 0;
   // committed sub-samples by levels reached (1..4, 5 and more): what the candidate set is built
   // from (static indices only - a register array indexed at run time would live in scratch)
   unsigned h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0;
+  int parity = 0;
 #if PTW_PROFILE_PHASES
-  unsigned long long stSteps = 0, stCommits = 0, stStarted = 0, stPrimary = 0, stSched = 0, stTrace = 0, stWait = 0,
-                     stBusy = 0;
+  unsigned long long stRounds = 0, stCommits = 0, stPrimary = 0, stFirst = 0, stChain = 0, stFold = 0, stWait = 0,
+                     stCommit = 0, stLevels = 0, stIdle = 0;
   const unsigned long long stT0 = __builtin_amdgcn_s_memtime();
 #define WT(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #else
 #define WT(var)
 #endif
-
-  // ---- this group's candidate (all per lane, equal within a group) ----
-  bool running = false;
-  int level = 1;      // depth of the ray the group holds
-  unsigned myKey = kNoNode;
-  Cursor cur;
-  cur.set(0, 0, 0);
-  int draws = 0;
-  unsigned rays = 0;
-  bool reflFirst = false;
-  unsigned long long stackBits = 0; // level i in bits [8i, 8i+8): combined index | lobe << 7
-  int nlev = 0;
-  d3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
 
   for (uint32_t i = 0; i < p.pixCount; ++i) {
     const uint32_t pix = p.pixBegin + i;
@@ -537,11 +512,8 @@ __global__ __launch_bounds__(kWideBlock) void traceSequentialWide(
     const int py = static_cast<int>(pix / static_cast<uint32_t>(w));
     // ---- every group: camera ray and first hit at the frontier (redundant, in parallel) ----
     WT(tP0);
-    {
-      Cursor c0;
-      c0.set(fOff, fQ, 0);
-      cur = c0;
-    }
+    Cursor cur;
+    cur.set(fOff, fQ, 0);
     double r0, r1, r2 = 0, r3 = 0;
     {
       const unsigned a = cur.canonAt();
@@ -551,6 +523,7 @@ __global__ __launch_bounds__(kWideBlock) void traceSequentialWide(
     const int camDraws = lens ? 4 : 2;
     d3 o, d;
     cameraRay(p.cam, px, py, r0, r1, r2, r3, o, d);
+    int sampleDraws = camDraws;
     d3 L = mk(0, 0, 0);
     bool traced = false;
     GroupHit k0;
@@ -580,13 +553,7 @@ __global__ __launch_bounds__(kWideBlock) void traceSequentialWide(
       }
       waveSync();
     }
-    // every slot starts the pixel free (one lane per slot of this wave writes its word)
-    if (sub == 0) slotNode[mySlot] = kNoNode, slotMeta[mySlot] = kSlotFree << 28;
-    running = false;
-    myKey = kNoNode;
-    advanceFrontier(camDraws); // (may regenerate a block: uniform, with barriers)
-    ldsBarrier();
-    int sampleDraws = camDraws;
+    advanceFrontier(camDraws); // (may regenerate a block: uniform)
 #if PTW_PROFILE_PHASES
     stPrimary += __builtin_amdgcn_s_memtime() - tP0;
 #endif
@@ -594,100 +561,28 @@ __global__ __launch_bounds__(kWideBlock) void traceSequentialWide(
       L = ldsD3(fs + 8 * kFsDiffuse); // Scene.cpp:137-138
     } else if (traced) {
       d3 result = mk(0, 0, 0);
-      int fj = 0, fS = 0; // the frontier: sub-sample index, draws since the pixel's first sub-sample
+      int j = 0;
       unsigned pixHist = 0; // 6-bit fields
-      for (;;) {
-        WT(tS0);
-        // ================= bookkeeping (identical in every wave): lane c looks at slot c =================
-        unsigned nodeV = kNoNode, metaV = kSlotFree << 28;
-        if (lane < kSlots) nodeV = slotNode[lane], metaV = slotMeta[lane];
-        d3 myL = mk(0, 0, 0);
-        if (wave == 0 && lane < kSlots) myL = mk(slotL[3 * lane], slotL[3 * lane + 1], slotL[3 * lane + 2]);
-        asm volatile("" : "+v"(nodeV), "+v"(metaV), "+v"(myL.x), "+v"(myL.y), "+v"(myL.z));
-        ldsBarrier(); // everybody has read the slots before anybody changes them
-        // ---- the frontier walks over the finished candidates that start where their predecessor stopped ----
-        int advanced = 0;
-        while (fj < nSub) {
-          const unsigned key = (static_cast<unsigned>(fj) << 16) | static_cast<unsigned>(fS);
-          const unsigned long long hit =
-              __builtin_amdgcn_ballot_w64(nodeV == key && (metaV >> 28) == kSlotDone);
-          if (hit == 0) break;
-          const int src = __builtin_ctzll(hit);
-          const unsigned meta = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(metaV), src));
-          const int cnt = static_cast<int>(meta & 0xffu);
-          raysTotal += (meta >> 16) & 0xfffu;
-          if (wave == 0) { // only the wave that stores the sample needs the radiance (and the statistics)
-            const d3 ch = mk(readLane(myL.x, src), readLane(myL.y, src), readLane(myL.z, src));
-            const d3 fe = ldsD3(fs + 8 * kFsEmission);
-            result = result + ((meta & 0x100u) ? fe + ch : fe + ldsD3(fs + 8 * kFsDiffuse) * ch);
-            const int levels = (cnt * 11) >> 5; // cnt / 3
-            pixHist += 1u << (6 * ((levels < 5 ? levels : 5) - 1));
-          }
-          fS += cnt;
-          advanced += cnt;
-          ++fj;
-#if PTW_PROFILE_PHASES
-          stCommits++;
-#endif
-        }
-        if (advanced) advanceFrontier(advanced); // (may regenerate a block: uniform, with barriers)
-        if (fj >= nSub) break;
-        // ---- slots the frontier has made pointless are free again: consumed, or contradicted ----
-        const int slotJ = static_cast<int>(nodeV >> 16), slotS = static_cast<int>(nodeV & 0xffffu);
-        const int dm = slotJ - fj, dD = slotS - fS;
-        const bool occupied = (metaV >> 28) != kSlotFree;
-        const bool dead = occupied && (dm < 0 || (dm == 0 && dD != 0) || dD < 3 * dm || dD > maxLevelDraws * dm);
-        const unsigned long long freeMask = __builtin_amdgcn_ballot_w64((!occupied || dead) && lane < kSlots);
-        // ---- which nodes of the ranked list (relative to the new frontier) are not in flight yet ----
-        auto wanted = [&](unsigned rk, unsigned &keyOut) {
-          const int j = fj + static_cast<int>(rk >> 8), S = fS + static_cast<int>(rk & 0xffu);
-          keyOut = (static_cast<unsigned>(j) << 16) | static_cast<unsigned>(S);
-          if (rk == 0xffffu || j >= nSub) return false;
-          const unsigned col = static_cast<unsigned>(S) / 3u;
-          if (col >= kPresentCols) return false;
-          const unsigned t = present[j * kPresentCols + col];
-          if (t == 0) return true;
-          const unsigned holder = t - 1u;
-          // the table may point to a slot that has moved on (or is being handed out this very step)
-          return !(slotNode[holder] == keyOut && !((freeMask >> holder) & 1ull));
-        };
-        unsigned key0, key1;
-        const bool want0 = wanted(rk0, key0), want1 = wanted(rk1, key1);
-        const unsigned long long n0 = __builtin_amdgcn_ballot_w64(want0), n1 = __builtin_amdgcn_ballot_w64(want1);
-        // the k-th free slot takes the k-th wanted node: compact the wanted nodes (rank order) ...
-        const unsigned below = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(n0 >> 32),
-                                                         __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(n0), 0u));
-        const unsigned below1 = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(n1 >> 32),
-                                                          __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(n1), 0u));
-        const unsigned nWant0 = static_cast<unsigned>(__builtin_popcountll(n0));
-        const unsigned nWant = nWant0 + static_cast<unsigned>(__builtin_popcountll(n1));
-        waveSync();
-        if (want0) compact[below] = static_cast<uint16_t>(rk0);
-        if (want1) compact[nWant0 + below1] = static_cast<uint16_t>(rk1);
-        waveSync();
-        // ... and let every group look up its own slot's turn
-        const bool slotFree = (freeMask >> mySlot) & 1ull;
-        const unsigned turn = static_cast<unsigned>(__builtin_popcountll(freeMask & ((1ull << mySlot) - 1ull)));
-        const bool assigned = slotFree && turn < nWant;
-        if (slotFree) { // what the group was doing (if anything) is pointless now
-          running = false;
-          myKey = kNoNode;
-        }
-        if (assigned) {
-          // ---- a new candidate: sub-sample fj + m, D draws after the frontier; its first-bounce
-          //      scatter (Scene.cpp:157-175 at depth 0) ----
-          const unsigned rk = compact[turn];
-          const int myIdx = fj + static_cast<int>(rk >> 8), myD = static_cast<int>(rk & 0xffu);
-          myKey = (static_cast<unsigned>(myIdx) << 16) | static_cast<unsigned>(fS + myD);
-          cur.set(fOff, fQ, myD);
+      while (j < nSub) {
+        WT(tR0);
+        // ---- this group's candidate: sub-sample j + myM, stream position frontier + myD ----
+        const int myIdx = j + myM;
+        bool alive = myIdx < nSub; // (an unused group carries node 0xffff: myM = 255)
+        cur.set(fOff, fQ, alive ? myD : 0);
+        int draws = 0;
+        unsigned rays = 0;
+        bool reflFirst = false;
+        unsigned long long stackBits = 0; // level i in bits [8i, 8i+8): combined index | lobe << 7
+        int nlev = 0;
+        d3 ro = ldsD3(fs + 8 * kFsPos), rd = mk(0, 0, 1);
+        d3 child = mk(0, 0, 0);
+        const bool candidate = alive;
+        if (alive) {
+          // the first-bounce scatter (Scene.cpp:157-175 at depth 0) of sub-sample myIdx
           const unsigned a = cur.canonAt();
           const double xu = ldsD(a), xv = ldsD(a + 8), pd = ldsD(a + 16);
           cur.advance(3);
           draws = 3;
-          rays = 0;
-          stackBits = 0;
-          nlev = 0;
-          level = 1;
           double u, v;
           if (fastFan) {
             const int uS = myIdx >> vShift, vS = myIdx & vMask;
@@ -700,7 +595,6 @@ __global__ __launch_bounds__(kWideBlock) void traceSequentialWide(
             v = p.vPow2 ? vr * p.invV : vr / static_cast<double>(p.fbV);
           }
           const d3 fn = ldsD3(fs + 8 * kFsNormal);
-          ro = ldsD3(fs + 8 * kFsPos);
           if (pd < ldsD(fs + 8 * kFsReflectivity)) { // Scene.cpp:163-168
             rd = coneSample(reflect(fn, ldsD3(fs + 8 * kFsDir)), ldsD(fs + 8 * kFsCone), u, v);
             reflFirst = true;
@@ -708,41 +602,33 @@ __global__ __launch_bounds__(kWideBlock) void traceSequentialWide(
             Basis fb;
             fb.x = ldsD3(fs + 8 * kFsBasisX), fb.y = ldsD3(fs + 8 * kFsBasisY), fb.z = fn;
             rd = hemisphereSample(fb, u, v); // Scene.cpp:169-175
-            reflFirst = false;
           }
-          running = true;
+          if (maxDepth <= 1) alive = false; // radiance(depth 1 >= maxDepth) = 0 (Scene.cpp:128)
         }
-        if (sub == 0 && slotFree) { // one lane per slot keeps the shared words current
-          slotNode[mySlot] = myKey;
-          slotMeta[mySlot] = (assigned ? kSlotRunning : kSlotFree) << 28;
-          if (assigned) present[(myKey >> 16) * kPresentCols + (myKey & 0xffffu) / 3u] = static_cast<unsigned char>(mySlot + 1);
-        }
+        // ---- the chain below the first bounce, level-synchronous over the wave's groups ----
 #if PTW_PROFILE_PHASES
-        stStarted += assigned && sub == 0;
-        stBusy += running && sub == 0;
         asm volatile("" : "+v"(rd.x));
-        WT(tS1);
+        WT(tR1);
+        stIdle += !candidate;
 #endif
-        // ================= one level for every running candidate of this wave =================
-        bool finished = false;
-        d3 child = mk(0, 0, 0);
-        if (running && level >= maxDepth) { // radiance(depth >= maxDepth) = 0 without a ray (Scene.cpp:128)
-          finished = true;
-        }
-        if (__builtin_amdgcn_ballot_w64(running && !finished) != 0) {
+        for (int level = 1; level < maxDepth; ++level) {
+          if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
+#if PTW_PROFILE_PHASES
+          stLevels++;
+#endif
           const GroupHit k = geom.intersect(p, ro, rd, sub);
-          if (running && !finished) {
+          if (alive) {
             rays++;
             if (k.code == kCodeMiss) { // Scene.cpp:131-133
               child = envColour;
-              finished = true;
+              alive = false;
             } else if (level + 1 >= maxDepth) {
               // last level: the child is radiance(depth >= maxDepth) = 0, so this level is its
               // emission whatever the lobe; only the three draws it consumes matter
               cur.advance(3);
               draws += 3;
               child = ldsD3(tab.emissionOf(k.code >> 1, nsph));
-              finished = true;
+              alive = false;
             } else {
               const uint32_t idx = k.code >> 1;
               const bool backfacing = (k.code & 1u) != 0;
@@ -771,36 +657,84 @@ __global__ __launch_bounds__(kWideBlock) void traceSequentialWide(
               draws += 3;
               stackBits |= static_cast<unsigned long long>((idx & 0x7fu) | (refl ? 0x80u : 0u)) << (8 * nlev);
               ++nlev;
-              ++level;
               ro = pos;
               rd = nd;
             }
           }
         }
-        if (__builtin_amdgcn_ballot_w64(finished) != 0) {
-          // fold innermost-first: L_level = E + T * L_child (Scene.cpp:163-175), then publish
-          if (finished) {
-            for (int lv = nlev - 1; lv >= 0; --lv) {
-              const unsigned wd = static_cast<unsigned>(stackBits >> (8 * lv)) & 0xffu;
-              const uint32_t idx = wd & 0x7fu;
-              const d3 e = ldsD3(tab.emissionOf(idx, nsph)), df = ldsD3(tab.diffuseOf(idx, nsph));
-              child = (wd & 0x80u) ? e + child : e + df * child;
-            }
-            if (sub == 0) {
-              slotL[3 * mySlot] = child.x, slotL[3 * mySlot + 1] = child.y, slotL[3 * mySlot + 2] = child.z;
-              slotMeta[mySlot] = (kSlotDone << 28) | (rays << 16) | (reflFirst ? 0x100u : 0u) | static_cast<unsigned>(draws);
-            }
-            running = false; // (the slot stays taken - its key stays in slotNode - until the frontier passes it)
+        // fold innermost-first: L_level = E + T * L_child (Scene.cpp:163-175)
+#if PTW_PROFILE_PHASES
+        asm volatile("" : "+v"(child.x));
+        WT(tR2);
+#endif
+        for (int lv = maxDepth - 3; lv >= 0; --lv) {
+          if (__builtin_amdgcn_ballot_w64(lv < nlev) == 0) continue;
+          if (lv < nlev) {
+            const unsigned wd = static_cast<unsigned>(stackBits >> (8 * lv)) & 0xffu;
+            const uint32_t idx = wd & 0x7fu;
+            const d3 e = ldsD3(tab.emissionOf(idx, nsph)), df = ldsD3(tab.diffuseOf(idx, nsph));
+            child = (wd & 0x80u) ? e + child : e + df * child;
           }
         }
-        WT(tS2);
-        ldsBarrier(); // results visible to everybody
+        // ---- publish ----
+        const unsigned resBase = kOffResults + static_cast<unsigned>(parity * kWideMaxCand) * sizeof(WideResult);
+        if (sub == 0 && myCand < kWideMaxCand) {
+          WideResult *slot = reinterpret_cast<WideResult *>(wideLds + resBase) + myCand;
+          slot->L[0] = child.x, slot->L[1] = child.y, slot->L[2] = child.z;
+          slot->meta = candidate ? (draws | (reflFirst ? 0x100 : 0) | static_cast<int>(rays << 16)) : 0;
+        }
+        WT(tR3);
+        ldsBarrier();
+        WT(tR4);
+        // ---- commit: walk the chain of candidates that started where their predecessor stopped
+        //      (identical in every wave): candidate 0 is the frontier itself; candidate c's
+        //      successor for the count it consumed comes from the table of the candidate set ----
+        // Lane c prepares, in parallel, what the walk needs to know about candidate c: its draw
+        // count, its rays, and the candidate that continues it (63: none in the set).
+        const WideResult *res = reinterpret_cast<const WideResult *>(wideLds + resBase);
+        const int metaV = lane < nCand ? res[lane].meta : 0;
+        int packV;
+        {
+          const int cnt = metaV & 0xff;
+          const int levels = (cnt * 11) >> 5; // cnt / 3 for cnt <= 27
+          unsigned next = levels >= 1 && levels <= 5 ? (succV >> (6 * (levels - 1))) & 63u : 63u;
+          packV = static_cast<int>(next | (static_cast<unsigned>(metaV & 0xff) << 8) |
+                                   (static_cast<unsigned>(metaV >> 16) << 16));
+        }
+        int m = 0, D = 0;
+        unsigned raysRound = 0;
+        unsigned long long chain = 0; // committed candidate indices, 6 bits each (at most 10 are kept)
+        for (int c = 0; c != 63 && j + m < nSub;) {
+          const unsigned wd = static_cast<unsigned>(__builtin_amdgcn_readlane(packV, c));
+          chain |= static_cast<unsigned long long>(c) << (6 * m);
+          D += static_cast<int>((wd >> 8) & 0xffu);
+          raysRound += wd >> 16;
+          ++m;
+          c = m < 10 ? static_cast<int>(wd & 63u) : 63;
+        }
+        raysTotal += raysRound;
+        if (wave == 0) { // only the wave that stores the sample needs the radiance (and the statistics)
+          const d3 myL = lane < nCand ? mk(res[lane].L[0], res[lane].L[1], res[lane].L[2]) : mk(0, 0, 0);
+          const d3 fe = ldsD3(fs + 8 * kFsEmission), fd = ldsD3(fs + 8 * kFsDiffuse);
+          for (int q = 0; q < m; ++q) {
+            const int src = static_cast<int>((chain >> (6 * q)) & 63u);
+            const int meta = __builtin_amdgcn_readlane(metaV, src);
+            const d3 ch = mk(readLane(myL.x, src), readLane(myL.y, src), readLane(myL.z, src));
+            result = result + ((meta & 0x100) ? fe + ch : fe + fd * ch);
+            const int levels = ((meta & 0xff) * 11) >> 5;
+            pixHist += 1u << (6 * ((levels < 5 ? levels : 5) - 1));
+          }
+        }
+        j += m;
+        sampleDraws += D;
+        parity ^= 1;
+        advanceFrontier(D); // (may regenerate a block: uniform)
 #if PTW_PROFILE_PHASES
-        stSteps++;
-        stSched += tS1 - tS0, stTrace += tS2 - tS1, stWait += __builtin_amdgcn_s_memtime() - tS2;
+        stRounds++, stCommits += m;
+        stFirst += tR1 - tR0, stChain += tR2 - tR1, stFold += tR3 - tR2, stWait += tR4 - tR3;
+        stCommit += __builtin_amdgcn_s_memtime() - tR4;
 #endif
       }
-      sampleDraws += fS;
       L = result * p.invFirstBounce;
       h1 += pixHist & 63u, h2 += (pixHist >> 6) & 63u, h3 += (pixHist >> 12) & 63u;
       h4 += (pixHist >> 18) & 63u, h5 += (pixHist >> 24) & 63u;
@@ -816,11 +750,12 @@ __global__ __launch_bounds__(kWideBlock) void traceSequentialWide(
 #if PTW_PROFILE_PHASES
   if (pass == 0 && lane == 0) {
     const double n = static_cast<double>(p.pixCount);
-    printf("WIDE<%d,%d,%d> wave %d: cycles/sample=%.0f steps/sample=%.2f commits/step=%.2f started/sample=%.1f "
-           "busy groups/step=%.2f | per sample: primary=%.0f bookkeeping=%.0f level=%.0f wait=%.0f\n",
-           G, SLOTS, SPH, wave, (__builtin_amdgcn_s_memtime() - stT0) / n, stSteps / n,
-           static_cast<double>(stCommits) / stSteps, stStarted / n, static_cast<double>(stBusy) / stSteps,
-           stPrimary / n, stSched / n, stTrace / n, stWait / n);
+    printf("WIDE<%d,%d> wave %d: cycles/sample=%.0f rounds/sample=%.2f commits/round=%.2f levels/round=%.2f "
+           "idle=%.2f | per sample: primary=%.0f first=%.0f chain=%.0f fold+publish=%.0f wait=%.0f commit=%.0f\n",
+           G, SLOTS, wave, (__builtin_amdgcn_s_memtime() - stT0) / n, stRounds / n,
+           static_cast<double>(stCommits) / stRounds, static_cast<double>(stLevels) / stRounds,
+           static_cast<double>(stIdle) / stRounds, stPrimary / n, stFirst / n, stChain / n, stFold / n,
+           stWait / n, stCommit / n);
   }
 #endif
   if (threadIdx.x == 0) {
@@ -888,14 +823,26 @@ __global__ __launch_bounds__(64) void wideBuildCandidates(unsigned long long *__
     maxD = 3 * bk > maxD ? 3 * bk : maxD;
     expand(bm, bk, best);
   }
-  for (int i = count; i < kWideRanked; ++i) out->node[i] = 0xffffu;
+  for (int i = count; i < kWideMaxCand; ++i) out->node[i] = 0xffffu;
+  for (int i = 0; i < kWideMaxCand; ++i) {
+    uint32_t row = 0;
+    for (int c = 1; c <= 5; ++c) {
+      uint32_t next = 63;
+      if (i < count) {
+        const int m = out->node[i] >> 8, k = (out->node[i] & 0xff) / 3;
+        if (m + 1 < kCandMaxM && k + c < kCandMaxK && taken[m + 1][k + c]) next = taken[m + 1][k + c] - 1u;
+      }
+      row |= next << (6 * (c - 1));
+    }
+    out->succ[i] = row;
+  }
   out->count = count;
   out->maxD = maxD;
 }
 
-template <int G, int SLOTS, int SPH>
-hipError_t launchWideK(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
-  auto kernel = traceSequentialWide<G, SLOTS, SPH>;
+template <int G, int SLOTS>
+hipError_t launchWide(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
+  auto kernel = traceSequentialWide<G, SLOTS>;
   const size_t lds = wideLdsBytes(p.ntri, p.nmat, p.nsph);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -906,17 +853,11 @@ hipError_t launchWideK(const TraceParams &p, const TraceBuffers &b, hipStream_t 
   return hipGetLastError();
 }
 
-template <int G, int SLOTS>
-hipError_t launchWide(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
-  if (p.nsph <= static_cast<uint32_t>(G)) return launchWideK<G, SLOTS, 1>(p, b, stream);
-  return launchWideK<G, SLOTS, 2>(p, b, stream);
-}
-
 } // namespace
 
 bool wideKernelApplies(const TraceParams &p) {
   return p.ntri <= 64u && p.nsph <= static_cast<uint32_t>(8 * kWideSphereSlots) &&
-         p.nsph + p.ntri <= 127 && p.maxDepth <= 9 && p.fbU * p.fbV >= 1 && p.fbU * p.fbV <= kWideMaxSub &&
+         p.nsph + p.ntri <= 127 && p.maxDepth <= 9 && p.fbU * p.fbV >= 1 &&
          wideLdsBytes(p.ntri, p.nmat, p.nsph) <= 150 * 1024;
 }
 
@@ -931,8 +872,7 @@ hipError_t launchTraceSequentialWide(const TraceParams &p, const TraceBuffers &b
   int G = p.ntri <= 40 ? 8 : 16;
   if (gEnv && (std::atoi(gEnv) == 8 || std::atoi(gEnv) == 16)) G = std::atoi(gEnv);
   if (G == 8 && p.ntri > 40) G = 16;
-  (void)G;
-  int n = kWideRanked;
+  int n = kWideWaves * 64 / G;
   if (nEnv) n = std::max(1, std::min(n, std::atoi(nEnv)));
   // the candidate set for this band, from what the previous band measured.  A round reads up to
   // maxD + 3 maxDepth draws beyond the frontier and only the frontier's block and the next one
