@@ -146,7 +146,11 @@ class Shard:
                 self.total_spp = args.spp
                 self.scaling = "strong"
                 self.parallelism = (f"{args.spp} passes split over {world} GPUs + one RCCL reduce(sum) of the "
-                                    "fp64 framebuffer (ptw_comm_reduce_framebuffer)")
+                                    "fp64 framebuffer (ptw_comm_reduce_framebuffer).  Under this policy a pass "
+                                    "is ONE serial chain over the frame's pixels (the reference's RNG assignment), "
+                                    "so more GPUs do not shorten a frame of <= 256 passes - they leave CUs idle; "
+                                    "the tile-sharded strong scaling north_star describes is the perpixel_policy "
+                                    "object of this line")
             else:
                 first_pass, spp = sharding.weak_pass_shard(rank, args.spp)
                 self.merge = "reduce"
@@ -452,34 +456,53 @@ def main():
             "resolve_kernel_ms_total": stats.resolve_ms,
         }
 
-    # -- the other RNG policy, same workload, same run (N = 1 only) ---------------------------
-    if world == 1 and not args.no_secondary and policy == pkg.RNG_SEQUENTIAL and not args.rows:
+    # -- the other RNG policy, same workload, same run: at N > 1 it is the tile-sharded form
+    #    north_star words (image rows interleaved over the GPUs + one RCCL gather) ---------------
+    if not args.no_secondary and policy == pkg.RNG_SEQUENTIAL and not args.rows:
         p2 = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=args.seed,
-                                rng_policy=pkg.RNG_PERPIXEL)
+                                rng_policy=pkg.RNG_PERPIXEL, device=local_rank,
+                                **(sharding.interleaved_rows(rank, world) if world > 1 else {}))
         rgb2 = torch.zeros_like(final[0])
         cnt2 = torch.zeros_like(final[1])
+        stream = torch.cuda.current_stream().cuda_stream
         ctx.enable_stats(True)
         ctx.stats(reset=True)
+        if use_dist:
+            dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ctx.render(cam, p2, rgb2.data_ptr(), cnt2.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        ctx.render(cam, p2, rgb2.data_ptr(), cnt2.data_ptr(), 0, stream)
+        if shard.comm is not None:
+            shard.comm.gather_rows(rgb2, cnt2, dst=0, stream=stream)
         torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
         dt2 = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt2], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt2 = float(t.item())
         s2 = ctx.stats(reset=True)
         ctx.enable_stats(False)
-        fl = s2.rays * (ntri * FLOP_PER_TRI_TEST + nsph * FLOP_PER_SPHERE_TEST)
-        tf = fl / (s2.trace_ms / 1e3) / 1e12
-        result["perpixel_policy"] = {
-            "value": w * h * spp / dt2 / 1e6, "unit": "Msamples/s", "ms_per_step": dt2 * 1e3,
-            "roofline": {"bound": "valu_fp64", "kernel": s2.trace_kernel.decode(), "achieved": tf,
-                         "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tf / FP64_VALU_PEAK_TFLOPS,
-                         "avg_launch_ms": s2.trace_ms / max(1, s2.trace_launches)},
-            "note": "same estimator and workload, independent sfc32 stream per (pass, pixel); "
-                    "not seed-matched with the reference; exact vs the oracle under the same policy",
-            "mean_abs_diff_vs_sequential_image":
-                float((rgb2 / spp - final[0] / spp).abs().mean().item()),
-        }
+        if rank == 0:
+            fl = s2.rays * (ntri * FLOP_PER_TRI_TEST + nsph * FLOP_PER_SPHERE_TEST)
+            tf = fl / (s2.trace_ms / 1e3) / 1e12
+            result["perpixel_policy"] = {
+                "value": w * h * spp / dt2 / 1e6, "unit": "Msamples/s", "ms_per_step": dt2 * 1e3, "n_gpus": world,
+                "scaling": "strong",
+                "parallelism": "single GPU" if world == 1 else
+                               f"image rows interleaved over {world} GPUs + one RCCL gather of the rows "
+                               "(ptw_comm_gather_rows); all counts on rank 0 checked",
+                "frame_complete_on_root": bool((cnt2 == spp).all().item()),
+                "roofline": {"bound": "valu_fp64", "kernel": s2.trace_kernel.decode(), "achieved": tf,
+                             "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": tf / FP64_VALU_PEAK_TFLOPS, "rank": 0,
+                             "avg_launch_ms": s2.trace_ms / max(1, s2.trace_launches)},
+                "note": "same estimator and workload, independent sfc32 stream per (pass, pixel); "
+                        "not seed-matched with the reference; exact vs the oracle under the same policy",
+                "mean_abs_diff_vs_sequential_image":
+                    float((rgb2 / spp - final[0] / max(1, shard.total_spp)).abs().mean().item()),
+            }
         del rgb2, cnt2
 
     if rank == 0 and world == 1 and (not args.no_cpu_baseline or not args.no_parity):
