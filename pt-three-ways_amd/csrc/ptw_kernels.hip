@@ -1647,10 +1647,32 @@ struct PixCtxT {
       return key;
     }
     if (ntri < 128) { // short lists: the plain loop (compiler-scheduled) is fastest
+#if PTW_PIX_SELECT
+      // rejection by select instead of branches (the lanes of a wave hold unrelated rays: a branch
+      // is skipped only when all 64 reject at the same stage)
+      for (uint32_t k = 0; k < ntri; ++k) {
+        const double *g = triGeom + 9 * static_cast<size_t>(k);
+        const d3 v0 = ld3(g), e1 = ld3(g + 3), e2 = ld3(g + 6);
+        const d3 pVec = cross(d, e2);
+        const double det = dot(e1, pVec);
+        const double invDet = rcp(det);
+        const d3 tVec = o - v0;
+        const double u = dot(tVec, pVec) * invDet;
+        const d3 qVec = cross(tVec, e1);
+        const double v = dot(d, qVec) * invDet;
+        const double t = dot(e2, qVec) * invDet;
+        const bool reject = (__builtin_fabs(det) < kEpsilon) | (u < 0.0) | (u > 1.0) | (v < 0.0) | (u + v > 1);
+        const bool take = !reject & (t > kEpsilon) & (t < key.t);
+        key.t = take ? t : key.t;
+        key.idx = take ? nsph + k : key.idx;
+        key.det = take ? det : key.det;
+      }
+#else
       for (uint32_t k = 0; k < ntri; ++k) {
         const double *g = triGeom + 9 * static_cast<size_t>(k);
         testTriangle(o, d, ld3(g), ld3(g + 3), ld3(g + 6), nsph + k, key.t, key.idx, key.det);
       }
+#endif
     } else {
       // wave-uniform scalar loads, one triangle ahead (see tracePerPixelPersistent)
       TriRegs cur = loadTriUniform(triGeom, 0);
@@ -1694,6 +1716,9 @@ constexpr int kPixBlock = 256;
 #endif
 #ifndef PTW_PIX2_WAVES
 #define PTW_PIX2_WAVES 4
+#endif
+#ifndef PTW_PIX_SELECT
+#define PTW_PIX_SELECT 0
 #endif
 
 // 4 waves per SIMD: the (E, T) stack is one word per level, so registers are what limits
