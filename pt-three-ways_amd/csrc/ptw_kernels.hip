@@ -45,6 +45,11 @@
 #ifndef PTW_PROFILE_PHASES
 #define PTW_PROFILE_PHASES 0
 #endif
+// -DPTW_SEQ_SELECT=1: worker lanes with several resident triangles reject by select instead of by
+// branch (A/B switch)
+#ifndef PTW_SEQ_SELECT
+#define PTW_SEQ_SELECT 0
+#endif
 #if PTW_PROFILE_PHASES
 #define PTW_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define PTW_ACC(slot, a, b) prof[slot] += (b) - (a)
@@ -533,10 +538,30 @@ struct SeqCtx {
         testSphere(o, d, ld3(r.centre), r.radiusSquared, i, bestT, bestIdx);
       }
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s)
+    for (int s = 0; s < SLOTS; ++s) {
+#if PTW_SEQ_SELECT
+      if (SLOTS > 1) { // several triangles per lane: rejection by select, no branch per test
+        const d3 v0 = mk(v0x[s], v0y[s], v0z[s]), e1 = mk(e1x[s], e1y[s], e1z[s]), e2 = mk(e2x[s], e2y[s], e2z[s]);
+        const d3 pVec = cross(d, e2);
+        const double det = dot(e1, pVec);
+        const double invDet = rcp(det);
+        const d3 tVec = o - v0;
+        const double u = dot(tVec, pVec) * invDet;
+        const d3 qVec = cross(tVec, e1);
+        const double v = dot(d, qVec) * invDet;
+        const double t = dot(e2, qVec) * invDet;
+        const bool reject = (__builtin_fabs(det) < kEpsilon) | (u < 0.0) | (u > 1.0) | (v < 0.0) | (u + v > 1);
+        const bool take = !reject & (t > kEpsilon) & (t < bestT);
+        bestT = take ? t : bestT;
+        bestIdx = take ? nsph + static_cast<uint32_t>(tid) * SLOTS + s : bestIdx;
+        bestDet = take ? det : bestDet;
+        continue;
+      }
+#endif
       testTriangle(o, d, mk(v0x[s], v0y[s], v0z[s]), mk(e1x[s], e1y[s], e1z[s]),
                    mk(e2x[s], e2y[s], e2z[s]), nsph + static_cast<uint32_t>(tid) * SLOTS + s,
                    bestT, bestIdx, bestDet);
+    }
     // rare: more triangles than resident slots -> stream the remainder from memory
     if (!REG && p->ntri > static_cast<uint32_t>(kThreads) * SLOTS)
       for (uint32_t k = static_cast<uint32_t>(kThreads) * SLOTS + tid; k < p->ntri; k += kThreads) {
