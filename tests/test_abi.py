@@ -63,6 +63,31 @@ def test_no_cpu_fallback_without_a_gpu(pkg):
     assert e.value.status == 2
 
 
+def test_argument_errors_are_reported_before_any_device_is_touched(pkg):
+    """ptw_render validates first: a bad request gets its own status even on a box without a GPU
+    (a zero fan-out used to reach the kernels; a row window under SEQUENTIAL was ignored)."""
+    scene = pkg.Scene()
+    cam = scene.build_named("single-sphere", 4, 4)
+
+    def status(**over):
+        with pytest.raises(pkg.PtwError) as e:
+            pkg.render(scene, cam, pkg.default_params(width=4, height=4, samples_per_pixel=1, seed=1, **over))
+        return e.value.status
+
+    assert status(first_bounce_u=0) == 1 and status(first_bounce_v=-1) == 1      # PTW_ERR_INVALID
+    assert status(first_bounce_u=2048, first_bounce_v=2048) == 1
+    assert status(max_depth=65) == 8                                              # PTW_ERR_UNSUPPORTED
+    assert status(row_begin=1, row_end=3) == 8 and status(row_stride=2) == 8      # SEQUENTIAL + row shard
+    assert status(rng_policy=1, row_begin=3, row_end=1) == 1
+    assert status(rng_policy=1, row_stride=2, row_phase=2) == 1
+    assert status(accel=1) == 8 and status(rng_policy=1, accel=7) == 1
+    assert status(rng_policy=5) == 1
+    # multi-device requests: update callbacks are single-device, negative counts are invalid
+    with pytest.raises(pkg.PtwError):
+        pkg.render(scene, cam, pkg.default_params(width=4, height=4, samples_per_pixel=1, seed=1),
+                   num_devices=2, update=lambda *a: False)
+
+
 def test_product_does_not_link_or_reference_the_oracle(pkg):
     out = subprocess.run(["readelf", "-d", str(pkg.LIB_PATH)], check=True, capture_output=True,
                          text=True).stdout
