@@ -680,7 +680,10 @@ void renderMulti(const ptw_scene_view &scene, const ptw_camera &camera,
         check(hipStreamCreateWithFlags(&sh.stream, hipStreamNonBlocking), "hipStreamCreate");
         sh.rgb.reserve(npix * 3);
         sh.counts.reserve(npix);
-        if (g == 0) { // the caller's running sums live on the first device
+        // The caller's running sums (ArrayOutput +=): under the pass sharding they live on the first
+        // device and the reduce adds the others' passes; under the row sharding every device adds its
+        // rows to its own copy and the gather brings those rows - old content included - to the root.
+        if (g == 0 || !sequential) {
           sh.rgb.upload(rgbSum, npix * 3, sh.stream);
           sh.counts.upload(counts, npix, sh.stream);
         } else {

@@ -2301,6 +2301,11 @@ hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipS
     const uint32_t blocks = static_cast<uint32_t>((total + kPixBlock - 1) / kPixBlock);
     const int levels = p.maxDepth > 1 ? p.maxDepth - 1 : 1;
     const size_t lds = static_cast<size_t>(levels + kBvhStack) * kPixBlock * sizeof(uint32_t);
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tracePerPixelBvh),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+      if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(tracePerPixelBvh, dim3(blocks), dim3(kPixBlock), lds, stream, p, b);
     return hipGetLastError();
   }
@@ -2328,6 +2333,11 @@ hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipS
   const uint32_t blocks = static_cast<uint32_t>((total + kPixBlock - 1) / kPixBlock);
   const int levels = p.maxDepth > 1 ? p.maxDepth - 1 : 1;
   const size_t lds = static_cast<size_t>(levels) * kPixBlock * sizeof(uint32_t);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tracePerPixel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(tracePerPixel, dim3(blocks), dim3(kPixBlock), lds, stream, p, b);
   return hipGetLastError();
 }
