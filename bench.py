@@ -85,8 +85,8 @@ def parse_args():
                     help="bvh: the SEPARATE accelerated mode (perpixel policy; same image, culled tests) - never "
                          "the headline configuration")
     ap.add_argument("--rows", default="",
-                    help="BEGIN:END - PERPIXEL only: time a sub-run of the frame (image rows [BEGIN, END) of the "
-                         "full-size frame); the workload string says so")
+                    help="BEGIN:END - time a sub-run of the frame (image rows [BEGIN, END) of the full-size frame; "
+                         "under the sequential policy BEGIN must be 0: a prefix); the workload string says so")
     ap.add_argument("--cpu-threads", type=int, default=6)
     ap.add_argument("--cpu-frame", type=int, default=0,
                     help="edge of the square frame of the CPU legs (0: per scene, cornell 1024)")
@@ -167,8 +167,10 @@ class Shard:
             assert self.policy == pkg.RNG_PERPIXEL, "--accel bvh needs --policy perpixel"
             extra = dict(extra, accel=pkg.ACCEL_BVH)
         if args.rows:
-            assert self.policy == pkg.RNG_PERPIXEL and world == 1, "--rows needs --policy perpixel on one GPU"
+            assert world == 1, "--rows times a sub-run on one GPU"
             r0, r1 = (int(v) for v in args.rows.split(":"))
+            assert self.policy == pkg.RNG_PERPIXEL or r0 == 0, "under the sequential policy only a prefix 0:END"
+
             extra = dict(extra, row_begin=r0, row_end=r1)
             self.rows = r1 - r0
         self.params = pkg.default_params(width=args.width, height=args.height, samples_per_pixel=spp,

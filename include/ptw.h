@@ -113,8 +113,10 @@ typedef struct ptw_render_params {
    * width x height frame.  row_begin == row_end == 0 => all rows; row_begin == row_end != 0 =>
    * an empty shard (nothing is rendered); row_stride 0 or 1 => every row of the window.
    * Interleaved rows (stride = number of GPUs, phase = rank) balance the shards: what a pixel
-   * costs depends on what it sees.  A window or stride under PTW_RNG_SEQUENTIAL is
-   * PTW_ERR_UNSUPPORTED (pixels of a pass are serially dependent there: shard by first_pass). */
+   * costs depends on what it sees.  Under PTW_RNG_SEQUENTIAL the pixels of a pass are serially
+   * dependent (shard by first_pass): a stride, or a window that does not start at row 0, is
+   * PTW_ERR_UNSUPPORTED; a PREFIX [0, row_end) is allowed - it is exactly what the full render
+   * produces for those rows (timed sub-runs of very large frames). */
   int32_t row_begin;
   int32_t row_end;
   int32_t device;                /* HIP device ordinal for ptw_render()                     */

@@ -164,10 +164,14 @@ void validate(const ptw_render_params &p) {
     throw DeviceError(PTW_ERR_UNSUPPORTED,
                       "the accelerated mode needs PTW_RNG_PERPIXEL (the SEQUENTIAL kernels search the "
                       "scene cooperatively, a lane per primitive)");
-  if (p.rng_policy == PTW_RNG_SEQUENTIAL && (p.row_begin != 0 || p.row_end != 0 || p.row_stride > 1))
+  // Under PTW_RNG_SEQUENTIAL the pixels of a pass share one stream, consumed in row-major order: the
+  // only window that means anything is a PREFIX of the frame (rows [0, row_end): exactly what the
+  // full render produces for those rows - used for timed sub-runs of very large frames).
+  if (p.rng_policy == PTW_RNG_SEQUENTIAL && (p.row_begin != 0 || p.row_stride > 1))
     throw DeviceError(PTW_ERR_UNSUPPORTED,
                       "a row window needs PTW_RNG_PERPIXEL: under PTW_RNG_SEQUENTIAL the pixels of a "
-                      "pass share one stream (shard by first_pass instead)");
+                      "pass share one stream (shard by first_pass instead; only a prefix [0, row_end) "
+                      "of the frame can be rendered on its own)");
 }
 
 // The image rows a render covers: first row, row stride, number of rows.

@@ -77,7 +77,7 @@ def test_argument_errors_are_reported_before_any_device_is_touched(pkg):
     assert status(first_bounce_u=0) == 1 and status(first_bounce_v=-1) == 1      # PTW_ERR_INVALID
     assert status(first_bounce_u=2048, first_bounce_v=2048) == 1
     assert status(max_depth=65) == 8                                              # PTW_ERR_UNSUPPORTED
-    assert status(row_begin=1, row_end=3) == 8 and status(row_stride=2) == 8      # SEQUENTIAL + row shard
+    assert status(row_begin=1, row_end=3) == 8 and status(row_stride=2) == 8      # SEQUENTIAL + row shard (a prefix is fine)
     assert status(rng_policy=1, row_begin=3, row_end=1) == 1
     assert status(rng_policy=1, row_stride=2, row_phase=2) == 1
     assert status(accel=1) == 8 and status(rng_policy=1, accel=7) == 1

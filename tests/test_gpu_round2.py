@@ -145,6 +145,10 @@ def test_empty_shard_and_argument_errors(pkg):
     assert status(first_bounce_u=0) == 1 and status(first_bounce_v=0) == 1   # PTW_ERR_INVALID
     assert status(first_bounce_u=1 << 11, first_bounce_v=1 << 11) == 1
     assert status(row_begin=2, row_end=4) == 8                               # SEQUENTIAL + window: UNSUPPORTED
+    # ... except a prefix of the frame: exactly the rows the full render produces
+    full, _ = pkg.render(scene, cam, pkg.default_params(width=10, height=8, samples_per_pixel=3, seed=1))
+    part, pcnt = pkg.render(scene, cam, pkg.default_params(width=10, height=8, samples_per_pixel=3, seed=1, row_end=5))
+    assert np.array_equal(part[:5], full[:5]) and not part[5:].any() and np.all(pcnt[:5] == 3) and not pcnt[5:].any()
     assert status(row_stride=2, row_phase=0) == 8
     assert status(rng_policy=1, row_stride=2, row_phase=2) == 1
 
