@@ -253,7 +253,9 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   // the band before: give it a short first band to measure on and at least eight bands, so that
   // the set follows the image from top to bottom.
   static const char *wideEnv = std::getenv("PTW_SEQ_WIDE");
-  const bool adaptive = sequential && wideEnv && wideEnv[0] == '1' && wideKernelApplies(t) && pixTotal >= 16384;
+  static const char *spec8Env = std::getenv("PTW_SEQ_SPEC8");
+  const bool adaptive = sequential && pixTotal >= 16384 && ctx.ntri <= 64 &&
+                        ((wideEnv && wideEnv[0] == '1' && wideKernelApplies(t)) || (spec8Env && spec8Env[0] == '1'));
   if (adaptive) bandPix = std::min<uint64_t>(bandPix, (pixTotal + 7) / 8);
   // equal bands (the last one is not a sliver)
   const uint64_t nBands = (pixTotal + bandPix - 1) / bandPix;

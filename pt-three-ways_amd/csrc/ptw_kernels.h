@@ -74,6 +74,8 @@ hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hi
 // per-sub-sample draw counts the previous launch left in countHist.
 bool wideKernelApplies(const TraceParams &p);
 size_t wideCandidateBytes();
+// Builds the candidate set (n candidates) for the next launch from b.countHist into b.wideCands.
+hipError_t launchBuildCandidates(const TraceParams &p, const TraceBuffers &b, int n, hipStream_t stream);
 hipError_t launchTraceSequentialWide(const TraceParams &p, const TraceBuffers &b, hipStream_t stream,
                                      const char **variant);
 // PERPIXEL policy: one lane per (pass, pixel) sample.

@@ -175,5 +175,16 @@ __device__ __noinline__ void specGenerateBlock(uint32_t *x, char *ring, unsigned
 constexpr uint32_t kGenNone = 0, kGenSlot0 = 1, kGenSlot1 = 2, kGenExit = 3;
 
 
+// The candidate set of the many-candidate speculative kernels (device memory, written per band by
+// wideBuildCandidates in ptw_wide.hip from the measured histogram of per-sub-sample draw counts).
+constexpr int kWideMaxCand = 64;
+struct WideCandidates {
+  uint16_t node[kWideMaxCand]; // candidate c = m << 8 | D: sub-sample j + m, D draws after the frontier
+  uint32_t succ[kWideMaxCand]; // 6-bit fields: the candidate that continues c when c consumed 3 (k + 1)
+                               // draws, k = 0..4 (63: not in the set)
+  int32_t count;
+  int32_t maxD; // largest D in the list (how far ahead of the frontier a round reads)
+};
+
 } // namespace
 } // namespace ptw

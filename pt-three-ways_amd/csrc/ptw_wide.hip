@@ -62,7 +62,6 @@ namespace {
 
 constexpr int kWideWaves = 8;       // tracing waves: two per SIMD of the CU
 constexpr int kWideBlock = 64 * kWideWaves;
-constexpr int kWideMaxCand = 64;    // candidates per round: kWideWaves x 64 / G, one per lane in the walk
 constexpr int kWideSphereSlots = 2; // spheres per lane: up to 2 G spheres
 
 // LDS triangle record of this kernel (doubles): what a hit and a fold need, one fetch each.
@@ -73,15 +72,6 @@ struct alignas(16) WideResult { // one per candidate and round parity, in LDS
   double L[3]; // radiance of the sub-path below the first-bounce surface
   int meta;    // canonical doubles consumed | lobe at the first-bounce surface << 8 | rays << 16
   int pad;
-};
-
-// The candidate set of a band (device memory, written by wideBuildCandidates).
-struct WideCandidates {
-  uint16_t node[kWideMaxCand]; // candidate c = m << 8 | D: sub-sample j + m, D draws after the frontier
-  uint32_t succ[kWideMaxCand]; // 6-bit fields: the candidate that continues c when c consumed 3 (k + 1)
-                               // draws, k = 0..4 (63: not in the set)
-  int32_t count;
-  int32_t maxD; // largest D in the list (how far ahead of the frontier a round reads)
 };
 
 // ---- LDS layout (byte offsets into wideLds) ----
@@ -863,6 +853,15 @@ bool wideKernelApplies(const TraceParams &p) {
 
 size_t wideCandidateBytes() { return sizeof(WideCandidates); }
 
+hipError_t launchBuildCandidates(const TraceParams &p, const TraceBuffers &b, int n, hipStream_t stream) {
+  // A round reads up to maxD + 3 maxDepth draws beyond the frontier and only the frontier's block
+  // and the next one exist: candidates stay within 312 - 3 maxDepth - 8 draws of the frontier.
+  const int maxAhead = std::min(255, kMtDoubles - 3 * (p.maxDepth > 0 ? p.maxDepth : 1) - 8);
+  hipLaunchKernelGGL(wideBuildCandidates, dim3(1), dim3(64), 0, stream, b.countHist, n, p.fbU * p.fbV, maxAhead,
+                     reinterpret_cast<WideCandidates *>(b.wideCands));
+  return hipGetLastError();
+}
+
 hipError_t launchTraceSequentialWide(const TraceParams &p, const TraceBuffers &b, hipStream_t stream,
                                      const char **variant) {
   // G lanes per candidate: 8 (64 candidates per round) while the lane's share of the triangles fits
@@ -874,13 +873,8 @@ hipError_t launchTraceSequentialWide(const TraceParams &p, const TraceBuffers &b
   if (G == 8 && p.ntri > 40) G = 16;
   int n = kWideWaves * 64 / G;
   if (nEnv) n = std::max(1, std::min(n, std::atoi(nEnv)));
-  // the candidate set for this band, from what the previous band measured.  A round reads up to
-  // maxD + 3 maxDepth draws beyond the frontier and only the frontier's block and the next one
-  // exist: candidates stay within 312 - 3 maxDepth - 8 draws of the frontier.
-  const int maxAhead = std::min(255, kMtDoubles - 3 * (p.maxDepth > 0 ? p.maxDepth : 1) - 8);
-  hipLaunchKernelGGL(wideBuildCandidates, dim3(1), dim3(64), 0, stream, b.countHist, n, p.fbU * p.fbV, maxAhead,
-                     reinterpret_cast<WideCandidates *>(b.wideCands));
-  hipError_t e = hipGetLastError();
+  // the candidate set for this band, from what the previous band measured
+  hipError_t e = launchBuildCandidates(p, b, n, stream);
   if (e != hipSuccess) return e;
   auto pick = [&](const char *name) {
     if (variant) *variant = name;

@@ -68,6 +68,7 @@ def test_sequential_kernel_variants_write_identical_bytes(pkg, tmp_path, scene, 
     args = ["-w", "40", "-h", "28", "--spp", "5", "--seed", "11", "--scene", scene, "--raw", "--save-every", "0"] + extra
     variants = {"spec": {}, "reg": {"PTW_SEQ_SPEC": "0"}, "plain": {"PTW_SEQ_SPEC": "0", "PTW_SEQ_REG": "0"},
                 "spec_bands": {"PTW_STAGE_BUDGET_KB": "12"},
+                "spec8": {"PTW_SEQ_SPEC8": "1"}, "spec8_bands": {"PTW_SEQ_SPEC8": "1", "PTW_STAGE_BUDGET_KB": "12"},
                 "wide8": {"PTW_SEQ_WIDE": "1", "PTW_WIDE_G": "8"}, "wide16": {"PTW_SEQ_WIDE": "1", "PTW_WIDE_G": "16"},
                 "wide8_few": {"PTW_SEQ_WIDE": "1", "PTW_WIDE_CANDIDATES": "5"},
                 "wide_bands": {"PTW_SEQ_WIDE": "1", "PTW_STAGE_BUDGET_KB": "12"}}
