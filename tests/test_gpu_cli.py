@@ -80,6 +80,23 @@ def test_sequential_kernel_variants_write_identical_bytes(pkg, tmp_path, scene, 
         assert blobs[name] == blobs["plain"], name
 
 
+@pytest.mark.parametrize("scene,spp", [("suzanne", 5), ("ce", 2), ("ce", 3), ("suzanne", 1)])
+def test_two_master_worker_kernel_writes_identical_bytes(pkg, tmp_path, scene, spp):
+    """Scenes beyond 128 triangles: the kernel with two passes (two master waves) per workgroup over
+    six shared worker waves against the one-master kernel - same .raw bytes, for even and odd pass
+    counts (an odd count leaves the last workgroup one master without a pass) and when every pass
+    parks and resumes its generator between bands."""
+    from conftest import ROOT
+    args = ["-w", "24", "-h", "18", "--spp", str(spp), "--seed", "4", "--scene", scene, "--raw", "--save-every", "0"]
+    variants = {"one": {"PTW_SEQ_MM": "0"}, "two": {"PTW_SEQ_MM": "1"},
+                "two_bands": {"PTW_SEQ_MM": "1", "PTW_STAGE_BUDGET_KB": "8"}}
+    blobs = {}
+    for name, env in variants.items():
+        out = run_cli(pkg, args + [str(tmp_path / f"{name}.raw")], ROOT, env=env)
+        blobs[name] = (tmp_path / f"{name}.raw").read_bytes()
+    assert blobs["two"] == blobs["one"] and blobs["two_bands"] == blobs["one"]
+
+
 def test_gpus_flag_shards_passes_over_host_threads(pkg, tmp_path):
     """--gpus N: one host thread and context per device, pass ranges merged in device order.  On a
     1-GPU box the shards share the device (PTW_CLI_SHARE_DEVICE); the sum of the two partial frames
