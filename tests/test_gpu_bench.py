@@ -75,4 +75,4 @@ def test_bench_weak_flag_and_perpixel_policy():
                            "perpixel", "--no-cpu-baseline", "--no-parity"],
                           capture_output=True, text=True, timeout=900, cwd=ROOT)
     r = _json_line(proc)
-    assert r["scaling"] == "weak" and r["roofline"]["kernel"] == "tracePerPixel"
+    assert r["scaling"] == "weak" and r["roofline"]["kernel"] == "tracePerPixelPersistent"

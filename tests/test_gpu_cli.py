@@ -97,6 +97,23 @@ def test_two_master_worker_kernel_writes_identical_bytes(pkg, tmp_path, scene, s
     assert blobs["two"] == blobs["one"] and blobs["two_bands"] == blobs["one"]
 
 
+@pytest.mark.parametrize("scene", ["cornell", "suzanne", "multi-sphere"])
+def test_perpixel_kernel_variants_write_identical_bytes(pkg, tmp_path, scene):
+    """PERPIXEL policy: the persistent kernel at 2, 3 and 4 waves per SIMD and the lock-step kernel are
+    schedules of one computation: same .raw bytes."""
+    from conftest import ROOT
+    args = ["-w", "40", "-h", "28", "--spp", "3", "--seed", "9", "--scene", scene, "--rng", "perpixel", "--raw",
+            "--save-every", "0"]
+    variants = {"default": {}, "lockstep": {"PTW_PIX_KERNEL": "legacy"}, "w2": {"PTW_PIX2_W": "2"},
+                "w3": {"PTW_PIX2_W": "3"}, "w4": {"PTW_PIX2_W": "4"}}
+    blobs = {}
+    for name, env in variants.items():
+        run_cli(pkg, args + [str(tmp_path / f"{name}.raw")], ROOT, env=env)
+        blobs[name] = (tmp_path / f"{name}.raw").read_bytes()
+    for name in variants:
+        assert blobs[name] == blobs["default"], name
+
+
 def test_gpus_flag_shards_passes_over_host_threads(pkg, tmp_path):
     """--gpus N: one host thread and context per device, pass ranges merged in device order.  On a
     1-GPU box the shards share the device (PTW_CLI_SHARE_DEVICE); the sum of the two partial frames

@@ -186,7 +186,7 @@ def test_update_callback_hands_back_the_running_framebuffer(pkg):
 
 def test_kernel_variant_is_reported_by_the_library(pkg):
     import torch
-    cases = [("cornell", 0, "traceSequentialSpec"), ("cornell", 1, "tracePerPixel"),
+    cases = [("cornell", 0, "traceSequentialSpec"), ("cornell", 1, "tracePerPixelPersistent"),
              ("suzanne", 0, "traceSequential<3,7,lds,stack>"), ("suzanne", 1, "tracePerPixelPersistent")]
     for name, policy, want in cases:
         scene = pkg.Scene()
