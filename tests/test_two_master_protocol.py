@@ -129,3 +129,48 @@ def test_two_master_protocol_all_ray_counts():
         for seed in range(6):
             g2, b2 = run(rays0, rays1, has1, order_seed=seed)
             assert b2 == barriers and sorted(g2.log) == sorted(g.log) and sorted(g2.reads) == sorted(g.reads)
+
+
+def worker_rank(wave, masters, workers):
+    """traceSequential's `workerRank` (ptw_kernels.hip): `tid` order of the worker waves - the waves
+    that share a SIMD with a master (waves go to the four SIMDs round robin: wave 4 sits with wave 0,
+    wave 5 with wave 1) come last."""
+    r = wave - masters
+    first_shared, n_shared = 4 - masters, masters
+    if r >= first_shared + n_shared:
+        r -= n_shared
+    elif r >= first_shared:
+        r += workers - first_shared - n_shared
+    return r
+
+
+def test_slot_major_assignment_gives_the_empty_slots_to_the_waves_beside_a_master():
+    """SeqCtx::slotTriangle: slot s of lane `tid` holds triangle s * lanes + tid.  Every triangle has
+    exactly one holder, and the slots beyond the last triangle are empty in whole waves - the ones
+    with the highest rank, which are the ones on a master's SIMD."""
+    for masters, workers in ((1, 7), (2, 6)):
+        ranks = {wave: worker_rank(wave, masters, workers) for wave in range(masters, masters + workers)}
+        assert sorted(ranks.values()) == list(range(workers))
+        shared = [w for w in ranks if w % 4 < masters and w >= 4]      # same SIMD as a master wave
+        assert sorted(ranks[w] for w in shared) == list(range(workers - masters, workers))
+        lanes = 64 * workers
+        for slots, ntri in ((3, 970), (9, 3442), (2, 129), (4, 1536)):
+            if slots * lanes < ntri:
+                continue
+            holder = {}
+            for wave, rank in ranks.items():
+                for lane in range(64):
+                    tid = rank * 64 + lane
+                    for s in range(slots):
+                        k = s * lanes + tid
+                        if k < ntri:
+                            assert k not in holder
+                            holder[k] = (wave, s)
+            assert len(holder) == ntri
+            # a slot is either full in a wave, or empty in it, except in one wave per slot at most
+            for s in range(slots):
+                partial = [w for w in ranks if 0 < sum(1 for k, (hw, hs) in holder.items() if hw == w and hs == s) < 64]
+                assert len(partial) <= 1
+            # the waves beside a master never hold more than any other wave
+            load = {w: sum(1 for hw, _ in holder.values() if hw == w) for w in ranks}
+            assert max(load[w] for w in shared) <= min(load[w] for w in ranks if w not in shared)
