@@ -25,6 +25,11 @@ N > 1 (one process per GPU): STRONG scaling of the same frame by default (`--sca
               gather of the rows assembles the frame (ptw_comm_gather_rows).
 `--scaling weak` keeps 256 passes per GPU with distinct seeds (N x the samples).
 
+`--config cfg3|cfg4` selects the other single-GPU BASELINE configurations (suzanne 1024x1024 @ 512
+spp; ce 2048x2048 @ 1024 spp as a stated prefix sub-run of the frame) with the same JSON contract;
+the default cfg2 line also carries both, measured once each in the same run, as `other_configs`,
+and the strict-IEEE build's headline number as `strict_fp`.
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -58,8 +63,32 @@ HBM_BYTES_PER_SAMPLE_TRACE = 24.0
 CPU_SAMPLE_FRAME = {"cornell": 1024, "suzanne": 256, "ce": 64}
 
 
+# BASELINE.json configs that fit one GPU.  cfg4's frame takes 35 minutes whole under the sequential
+# policy (4.3e9 samples at ~2 Msamples/s): its line is a stated PREFIX sub-run (rows [0, rows_end) of
+# the 2048 x 2048 frame - under the sequential policy exactly what the full render produces for them).
+CONFIGS = {
+    "cfg2": dict(scene="cornell", width=1024, height=1024, spp=256, rows=""),
+    "cfg3": dict(scene="suzanne", width=1024, height=1024, spp=512, rows=""),
+    "cfg4": dict(scene="ce", width=2048, height=2048, spp=1024, rows="0:64"),
+}
+METRIC_NAMES = {"cornell": "CornellBox", "suzanne": "suzanne", "ce": "ce"}
+
+
+def metric_name(scene, w, h, spp):
+    if (scene, w, h, spp) == ("cornell", 1024, 1024, 256):
+        return "Msamples/sec CornellBox 1024²@256spp; per-channel RMSE vs DoD ref"   # BASELINE.json, verbatim
+    return f"Msamples/sec {METRIC_NAMES.get(scene, scene)} {w}x{h}@{spp}spp; per-channel RMSE vs DoD ref"
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                    help="a BASELINE.json configuration: sets --scene/--width/--height/--spp (and --rows for cfg4); "
+                         "default: cfg2, the one the metric is quoted on")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default cfg2 run: skip the one-shot cfg3 / cfg4 measurements (`other_configs`)")
+    ap.add_argument("--no-strict", action="store_true",
+                    help="default cfg2 run: skip the strict-IEEE build's headline leg (`strict_fp`)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
@@ -90,7 +119,13 @@ def parse_args():
     ap.add_argument("--cpu-threads", type=int, default=6)
     ap.add_argument("--cpu-frame", type=int, default=0,
                     help="edge of the square frame of the CPU legs (0: per scene, cornell 1024)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    args.is_default_workload = args.config in (None, "cfg2") and \
+        (args.scene, args.width, args.height, args.spp, args.rows) == ("cornell", 1024, 1024, 256, "")
+    if args.config:
+        for k, v in CONFIGS[args.config].items():
+            setattr(args, k, v)
+    return args
 
 
 def usable_cpus():
@@ -205,15 +240,33 @@ def timed_steps(shard, ctx, cam, bufs, steps, use_dist):
 
 
 # ---- CPU legs: the reference's own code on this box's host cores ----------------------------
-def ref_passes(ob, scene_name, view, params, passes, threads, want_words, on_pass=None):
-    """Runs the reference's pass loop (Scene.cpp:209-219, oracle/_ref) for the given pass indices on
-    `threads` host threads (one full-frame pass per thread at a time, like the reference's
-    std::async tasks) and hands every pass to `on_pass(pass_index, radiance, words)` IN PASS ORDER."""
-    rs = ob.RefScene(view, lib=ob.ref_fast)
-    desc = ob.cam_desc(**ob.SCENE_CAMERAS[scene_name])
+def reference_kind(ob, scene_name):
+    """("reference", ...) when oracle/_ref - the reference's own sources compiled where they lie - is on
+    this box, else ("port", ...): the strict C restatement oracle/ptw_oracle.c, which
+    tests/test_oracle_vs_ref.py pins to oracle/_ref bit for bit (radiance and RNG word counts).  A
+    clean checkout has no oracle/_ref (it is git-ignored and only travels with gpurun snapshots); the
+    parity number must not depend on it."""
+    if ob.ref_fast is not None and scene_name in ob.SCENE_CAMERAS:
+        return "reference"
+    return "port"
 
-    def one(k):
-        return k, rs.render_pass(desc, params, k, want_words=want_words)
+
+def ref_passes(ob, scene_name, view, cam, params, passes, threads, want_words, on_pass=None, strict=False):
+    """Runs the reference's pass loop (Scene.cpp:209-219) for the given pass indices on `threads` host
+    threads (one pass per thread at a time, like the reference's std::async tasks) and hands every
+    pass to `on_pass(pass_index, radiance, words)` IN PASS ORDER.  oracle/_ref when present, else the
+    restatement (`strict`: the -ffp-contract=off build of either)."""
+    if reference_kind(ob, scene_name) == "reference":
+        rs = ob.RefScene(view, lib=ob.ref if strict and ob.ref is not None else ob.ref_fast)
+        desc = ob.cam_desc(**ob.SCENE_CAMERAS[scene_name])
+
+        def one(k):
+            return k, rs.render_pass(desc, params, k, want_words=want_words)
+    else:
+        lib = ob.oracle if strict or ob.oracle_fast is None else ob.oracle_fast
+
+        def one(k):
+            return k, ob.oracle_render_pass(view, cam, params, k, lib=lib)
 
     with ThreadPoolExecutor(max_workers=threads) as pool:  # ctypes calls release the GIL
         for k, (rad, words) in pool.map(one, passes):      # map() yields in submission order
@@ -227,20 +280,15 @@ def cpu_leg(pkg, ob, scene_name, threads, passes, frame):
     cam = scene.build_named(scene_name, frame, frame)
     params = pkg.default_params(width=frame, height=frame, samples_per_pixel=passes, seed=1)
     n = frame * frame * passes
-    if ob.ref_fast is not None and scene_name in ob.SCENE_CAMERAS:
-        kind = "reference"
-        t0 = time.perf_counter()
-        ref_passes(ob, scene_name, scene.view(), params, list(range(passes)), threads, False)
-        dt = time.perf_counter() - t0
+    kind = reference_kind(ob, scene_name)
+    t0 = time.perf_counter()
+    ref_passes(ob, scene_name, scene.view(), cam, params, list(range(passes)), threads, False)
+    dt = time.perf_counter() - t0
+    if kind == "reference":
         what = ("reference dod::Scene::radiance + Camera::randomRay compiled from /root/reference/src "
                 "with -O2 -march=x86-64-v3 -funsafe-math-optimizations (oracle/_ref), pass loop of "
                 "Scene.cpp:209-219")
     else:
-        kind = "port"
-        lib = ob.oracle_fast or ob.oracle
-        t0 = time.perf_counter()
-        ob.oracle_render(scene.view(), cam, params, threads=threads, want_words=False, lib=lib)
-        dt = time.perf_counter() - t0
         what = "oracle/ptw_oracle.c (C restatement) built with the reference's optimisation flags"
     return {
         "value": n / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": kind,
@@ -251,29 +299,33 @@ def cpu_leg(pkg, ob, scene_name, threads, passes, frame):
     }
 
 
-def parity_vs_reference(pkg, ob, ctx, cam, view, args, threads):
-    """The metric's second half on the FULL frame: renders the frame once more on the GPU with
-    per-sample RNG word counts, runs the reference's own code for the same passes on all host
-    cores, and compares every pixel and every sample's word count."""
-    w, h = args.width, args.height
-    spp = args.spp if args.parity_passes <= 0 else min(args.spp, args.parity_passes)
-    params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=args.seed,
-                                rng_policy=pkg.RNG_SEQUENTIAL)
+def parity_vs_reference(pkg, ob, ctx, cam, view, scene_name, w, h, total_spp, seed, passes, rows_end, threads):
+    """The metric's second half: renders rows [0, rows_end) of the w x h frame once more on the GPU
+    with per-sample RNG word counts (rows_end == h: the whole frame), runs the reference's own code
+    for the same passes on the host cores, and compares every pixel and every sample's word count.
+    Under the sequential policy a prefix of the rows is exactly what the full render produces for
+    them, so a bounded comparison is still a comparison of the stated frame."""
+    spp = total_spp if passes <= 0 else min(total_spp, passes)
+    rows_end = min(rows_end, h)
+    window = dict(row_begin=0, row_end=rows_end) if rows_end < h else {}
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=seed,
+                                rng_policy=pkg.RNG_SEQUENTIAL, **window)
     rgb = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
     cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
     words = torch.zeros((spp, h, w), dtype=torch.int32, device="cuda")
     ctx.render(cam, params, rgb.data_ptr(), cnt.data_ptr(), words.data_ptr(),
                torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    gpu_sum = rgb.cpu().numpy()
-    gpu_cnt = cnt.cpu().numpy().astype(np.uint32)
+    gpu_sum = rgb.cpu().numpy()[:rows_end]
+    gpu_cnt = cnt.cpu().numpy().astype(np.uint32)[:rows_end]
 
-    ref_sum = np.zeros((h, w, 3))
+    ref_sum = np.zeros((rows_end, w, 3))
     stats = {"word_mismatch": 0, "words_total": 0, "where": []}
 
     def on_pass(k, rad, wd):   # pass order: output += pass (ArrayOutput.cpp:48-56)
-        np.add(ref_sum, rad, out=ref_sum)
-        gw = words[k].cpu().numpy().astype(np.uint32)
+        np.add(ref_sum, rad[:rows_end], out=ref_sum)
+        gw = words[k].cpu().numpy().astype(np.uint32)[:rows_end]
+        wd = wd[:rows_end]
         bad = np.argwhere(gw != wd)
         stats["word_mismatch"] += len(bad)
         for y, x in bad[:4]:
@@ -282,8 +334,9 @@ def parity_vs_reference(pkg, ob, ctx, cam, view, args, threads):
                                        "ref_words": int(wd[y, x])})
         stats["words_total"] += int(wd.sum(dtype=np.uint64))
 
+    kind = reference_kind(ob, scene_name)
     t0 = time.perf_counter()
-    ref_passes(ob, args.scene, view, params, list(range(spp)), threads, True, on_pass)
+    ref_passes(ob, scene_name, view, cam, params, list(range(spp)), threads, True, on_pass)
     dt = time.perf_counter() - t0
     del words
     mean_gpu = gpu_sum / np.maximum(gpu_cnt, 1)[..., None]
@@ -291,27 +344,137 @@ def parity_vs_reference(pkg, ob, ctx, cam, view, args, threads):
     diff = mean_gpu - mean_ref
     rmse = np.sqrt(np.mean(diff * diff, axis=(0, 1)))
     identical = np.all(gpu_sum == ref_sum, axis=2)
+    nsamp = int(w) * rows_end * spp
+    where = (f"every pixel of the {w}x{h} frame" if rows_end == h else
+             f"rows [0, {rows_end}) of the {w}x{h} frame (a prefix: what the full render produces for them)")
     return {
         "rmse_vs_ref": [float(x) for x in rmse],
         "max_abs_diff": float(np.max(np.abs(diff))),
-        "pixels_bit_identical": int(identical.sum()), "pixels": int(w * h),
-        "samples_word_count_differs": stats["word_mismatch"], "samples": int(w) * h * spp,
+        "pixels_bit_identical": int(identical.sum()), "pixels": int(w * rows_end),
+        "samples_word_count_differs": stats["word_mismatch"], "samples": nsamp,
         "word_count_differences": stats["where"],
         "counts_equal": bool(np.all(gpu_cnt == spp)),
-        "parity_passes": spp, "parity_note": f"every pixel of the {w}x{h} frame, passes [0, {spp}) of the "
-                                             f"{args.spp} (seeds {args.seed}..{args.seed + spp - 1}); the same "
-                                             "comparison over all 256 passes: profiles/r02e_bench_cornell1024_full.json",
-        "mean_words_per_sample": stats["words_total"] / float(w * h * spp),
-        "reference": "oracle/_ref: the reference's own src/dod/Scene.cpp + src/math + ArrayOutput compiled "
-                     "where they lie (-O2 -march=x86-64-v3 -funsafe-math-optimizations), pass loop of "
-                     "Scene.cpp:209-219, passes added in pass order",
-        "compared": "per-pixel means (sum / count, linear fp64) of the full frame; fp64 sums bitwise; "
-                    "RNG words consumed by every (pass, pixel) sample",
+        "parity_passes": spp,
+        "parity_note": f"{where}, passes [0, {spp}) of the {total_spp} (seeds {seed}..{seed + spp - 1}); all 256 "
+                       "passes of the headline frame: profiles/ (the round's *_full_parity.json)",
+        "mean_words_per_sample": stats["words_total"] / float(nsamp),
+        "reference_kind": kind,
+        "reference": ("oracle/_ref: the reference's own src/dod/Scene.cpp + src/math + ArrayOutput compiled "
+                      "where they lie (-O2 -march=x86-64-v3 -funsafe-math-optimizations), pass loop of "
+                      "Scene.cpp:209-219, passes added in pass order") if kind == "reference" else
+                     ("oracle/ptw_oracle.c, the C restatement (oracle/_ref is not on this box); "
+                      "tests/test_oracle_vs_ref.py pins it to the compiled reference bit for bit"),
+        "compared": "per-pixel means (sum / count, linear fp64); fp64 sums bitwise; RNG words consumed by "
+                    "every (pass, pixel) sample",
     }, {
-        "value": w * h * spp / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "reference",
-        "sample": f"{args.scene} {w}x{h}, {spp} full-frame passes on {threads} threads (the parity reference of "
-                  f"this run); {w * h * spp} samples in {dt:.1f} s; host: {cpu_model()}, {os.cpu_count()} logical "
-                  f"cores visible, {usable_cpus()} usable (affinity / cgroup quota)",
+        "value": nsamp / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": kind,
+        "sample": f"{scene_name} {w}x{h}, rows [0, {rows_end}), {spp} passes on {threads} threads (the parity "
+                  f"reference of this run); {nsamp} samples in {dt:.1f} s; host: {cpu_model()}, {os.cpu_count()} "
+                  f"logical cores visible, {usable_cpus()} usable (affinity / cgroup quota)",
+    }
+
+
+# Bounded parity windows of the side configurations (rows of the frame x passes): about 10-25 s of
+# host work each on six cores.
+SIDE_PARITY = {"cfg3": dict(rows_end=64, passes=6), "cfg4": dict(rows_end=4, passes=6)}
+
+
+def roofline_of(stats, ntri, nsph):
+    launches = max(1, stats.trace_launches)
+    avg_launch_s = stats.trace_ms / 1e3 / launches
+    flop_per_ray = ntri * FLOP_PER_TRI_TEST + nsph * FLOP_PER_SPHERE_TEST
+    achieved = stats.rays / launches * flop_per_ray / avg_launch_s / 1e12
+    return {
+        "bound": "valu_fp64", "kernel": stats.trace_kernel.decode() or "unknown",
+        "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": achieved / FP64_VALU_PEAK_TFLOPS,
+        "avg_launch_ms": avg_launch_s * 1e3, "launches": int(stats.trace_launches),
+        "algorithmic_flop_per_launch": stats.rays / launches * flop_per_ray,
+        "rays_per_sample": stats.rays / max(1, stats.samples),
+    }
+
+
+def side_config(pkg, ob, name, device, threads, want_parity):
+    """One BASELINE configuration other than the headline, measured ONCE in this run (a single
+    timed render, inputs resident in HBM) with the same fields as the main line."""
+    cfg = CONFIGS[name]
+    w, h, spp = cfg["width"], cfg["height"], cfg["spp"]
+    scene = pkg.Scene()
+    cam = scene.build_named(cfg["scene"], w, h)
+    view = scene.view()
+    ctx = pkg.Context(device)
+    ctx.set_scene(scene)
+    extra, rows = {}, h
+    if cfg["rows"]:
+        r0, r1 = (int(v) for v in cfg["rows"].split(":"))
+        extra, rows = dict(row_begin=r0, row_end=r1), r1 - r0
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=1, rng_policy=pkg.RNG_SEQUENTIAL,
+                                device=device, **extra)
+    rgb = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+    cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    # untimed: code objects + staging allocation with a one-row render of the same shape
+    ctx.render(cam, pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=1, rng_policy=pkg.RNG_SEQUENTIAL,
+                                       device=device, row_begin=0, row_end=1), rgb.data_ptr(), cnt.data_ptr(), 0, stream)
+    torch.cuda.synchronize()
+    rgb.zero_()
+    cnt.zero_()
+    ctx.enable_stats(True)
+    ctx.stats(reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.render(cam, params, rgb.data_ptr(), cnt.data_ptr(), 0, stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stats = ctx.stats(reset=True)
+    ctx.enable_stats(False)
+    out = {
+        "config": name, "metric": metric_name(cfg["scene"], w, h, spp),
+        "value": w * rows * spp / dt / 1e6, "unit": "Msamples/s", "n_gpus": 1, "steps": 1, "warmup": 0,
+        "ms_per_step": dt * 1e3, "dtype": "f64",
+        "workload": f"{cfg['scene']} {w}x{h} @ {spp} spp, maxDepth 5, 4x4 first bounce, rng_policy=sequential"
+                    + (f"; TIMED SUB-RUN: image rows [{cfg['rows'].replace(':', ', ')}) of the {w}x{h} frame "
+                       f"({rows}/{h} of its samples; the whole frame would take {dt * h / rows / 60:.0f} min)"
+                       if cfg["rows"] else ""),
+        "triangles": view.num_triangles, "spheres": view.num_spheres,
+        "frame_rows_complete": bool((cnt[:rows] == spp).all().item()),
+        "roofline": roofline_of(stats, view.num_triangles, view.num_spheres),
+    }
+    if want_parity:
+        par, leg = parity_vs_reference(pkg, ob, ctx, cam, view, cfg["scene"], w, h, spp, 1,
+                                       SIDE_PARITY[name]["passes"], SIDE_PARITY[name]["rows_end"], threads)
+        out.update(par)
+        out["cpu_leg"] = leg
+    del rgb, cnt
+    return out
+
+
+def strict_leg(args):
+    """The headline frame under the strict-IEEE build (libptw_hip_strict.so: no FMA contraction, IEEE
+    division and square root - the build whose every decision matches the reference's),
+    measured by this script in a child process so that the index-exact configuration has a measured
+    price next to the shipped one."""
+    import subprocess
+    lib = ROOT / "pt-three-ways_amd" / "libptw_hip_strict.so"
+    if not lib.exists():
+        return {"value": None, "note": "libptw_hip_strict.so is not built (make -C pt-three-ways_amd strict)"}
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "0", "--no-secondary",
+           "--no-cpu-baseline", "--no-other-configs", "--no-strict", "--parity-passes", str(max(4, min(args.parity_passes, 8)))]
+    try:
+        proc = subprocess.run(cmd, env=dict(os.environ, PTW_LIB_PATH=str(lib)), capture_output=True, text=True,
+                              timeout=600)
+        line = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1]
+        r = json.loads(line)
+    except Exception as e:  # noqa: BLE001
+        return {"value": None, "note": f"strict leg failed: {e!r}"}
+    return {
+        "value": r["value"], "unit": "Msamples/s", "ms_per_step": r["ms_per_step"], "steps": 1,
+        "flips": r.get("samples_word_count_differs"), "parity_passes": r.get("parity_passes"),
+        "rmse_vs_ref": r.get("rmse_vs_ref"), "pixels_bit_identical": r.get("pixels_bit_identical"),
+        "kernel": r["roofline"]["kernel"], "frac": r["roofline"]["frac"],
+        "build": "libptw_hip_strict.so: -ffp-contract=off -DPTW_FAST_MATH=0 (IEEE division and square root)",
+        "note": "same workload as `value`, one timed step in a child process of this run; `flips` = samples whose "
+                "RNG word count differs from the reference's over `parity_passes` whole-frame passes",
     }
 
 
@@ -415,11 +578,11 @@ def main():
         torch.cuda.synchronize()
         d2h_ms = (time.perf_counter() - t0) * 1e3
         result = {
-            "metric": "Msamples/sec CornellBox 1024²@256spp; per-channel RMSE vs DoD ref",
+            "metric": metric_name(args.scene, w, h, shard.total_spp),
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": shard.scaling, "vs_baseline": None, "dtype": "f64",
-            "data": "bundled scene (scenes/CornellBox-Original.obj + reference sphere), seed 1",
+            "data": f"bundled scene ({args.scene}: the reference's .obj + the primitives src/main/main.cpp adds), seed 1",
             "config": {
                 "workload": f"{args.scene} {w}x{h} @ {shard.total_spp} spp, maxDepth 5, 4x4 first bounce, "
                             f"rng_policy={args.policy}"
@@ -507,18 +670,40 @@ def main():
             }
         del rgb2, cnt2
 
+    if rank == 0 and world > 1:
+        # Machine-readable expectation for a reader of the scaling curve (the driver computes the
+        # efficiency itself): under the sequential policy a pass is ONE serial chain over the frame's
+        # pixels, so splitting <= 256 passes over more GPUs does not shorten the frame.
+        cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        per_rank = -(-args.spp // world) if shard.scaling == "strong" else args.spp
+        seq_expected = 1.0 if (shard.scaling == "strong" and args.spp <= cus) else \
+            (float(world) if shard.scaling == "weak" else min(float(world), max(1.0, args.spp / cus)))
+        result["scaling_expected"] = {
+            "value_policy": args.policy,
+            "sequential": {
+                "expected_speedup_vs_1gpu": seq_expected, "passes_per_gpu": per_rank, "cus_per_gpu": cus,
+                "why": "seed-matched policy: one mt19937 stream per pass consumed pixel after pixel (Scene.cpp:211-217) - "
+                       "the time of a frame is the time of ONE pass's chain while passes <= CUs; passes are the only "
+                       "thing the reference's RNG assignment leaves to shard (DESIGN.md 7)"},
+            "perpixel": {"expected_speedup_vs_1gpu": 0.9 * world,
+                         "why": "independent stream per (pass, pixel): interleaved rows + one gather; see perpixel_policy"},
+        }
     if rank == 0 and world == 1 and (not args.no_cpu_baseline or not args.no_parity):
         sys.path.insert(0, str(ROOT / "tests"))
         import oracle_binding as ob  # test infrastructure: the checker / the reported baseline only
         legs = []
         if not args.no_parity and policy == pkg.RNG_SEQUENTIAL:
-            if ob.ref_fast is not None and args.scene in ob.SCENE_CAMERAS:
-                parity, all_cores_leg = parity_vs_reference(pkg, ob, ctx, cam, view, args, usable_cpus())
-                result.update(parity)
-                legs.append(all_cores_leg)
+            rows_end = h
+            if args.rows:
+                rows_end = int(args.rows.split(":")[1])
+            if args.config in SIDE_PARITY:   # the large scenes: a bounded window (SIDE_PARITY)
+                rows_end, passes = SIDE_PARITY[args.config]["rows_end"], SIDE_PARITY[args.config]["passes"]
             else:
-                result["rmse_vs_ref"] = None
-                result["parity_note"] = "oracle/_ref is not built on this box"
+                passes = args.parity_passes
+            parity, all_cores_leg = parity_vs_reference(pkg, ob, ctx, cam, view, args.scene, w, h, spp, args.seed,
+                                                        passes, rows_end, usable_cpus())
+            result.update(parity)
+            legs.append(all_cores_leg)
         if not args.no_cpu_baseline:
             frame = args.cpu_frame or CPU_SAMPLE_FRAME.get(args.scene, 256)
             six = cpu_leg(pkg, ob, args.scene, args.cpu_threads, 2 * args.cpu_threads, frame)
@@ -526,6 +711,14 @@ def main():
             result["cpu_baseline"] = six       # the comparator north_star names: 6 threads
             legs = [one, six] + legs
         result["cpu_baseline_legs"] = legs
+        if args.is_default_workload and policy == pkg.RNG_SEQUENTIAL:
+            del scratch, final
+            torch.cuda.empty_cache()
+            if not args.no_other_configs:   # BASELINE cfg3 / cfg4, once each, same run
+                result["other_configs"] = [side_config(pkg, ob, name, local_rank, usable_cpus(), not args.no_parity)
+                                           for name in ("cfg3", "cfg4")]
+            if not args.no_strict:
+                result["strict_fp"] = strict_leg(args)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if shard.comm:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PTW_ABI_VERSION 2
+#define PTW_ABI_VERSION 3
 
 typedef enum ptw_status {
   PTW_OK = 0,
@@ -214,8 +214,12 @@ typedef struct ptw_render_options {
   void *progress_user;
   ptw_update_fn update;        /* may be NULL; single-device renders only                      */
   void *update_user;
-  int32_t share_device;        /* test hook for 1-GPU boxes: run the shards one after another
-                                  on params->device, accumulating on the device (no collective) */
+  int32_t share_device;        /* hosts with ONE GPU (and the tests): every shard on params->device.
+                                  1: the shards one after another, accumulated on the device, no
+                                     collective;
+                                  2: the N-GPU code path itself - a host thread, context and stream
+                                     per shard, the collective through the in-process loopback
+                                     transport (ptw_comm_create_loopback)                        */
   int32_t reserved[3];
 } ptw_render_options;
 int ptw_render_ex(const ptw_scene_view *scene, const ptw_camera *camera,
@@ -278,6 +282,15 @@ int ptw_comm_unique_id(uint8_t id_out[PTW_COMM_ID_BYTES]);
 int ptw_comm_create(const uint8_t id[PTW_COMM_ID_BYTES], int32_t world_size, int32_t rank,
                     int32_t device, ptw_comm **out);
 int ptw_comm_create_all(int32_t num_devices, const int32_t *devices, ptw_comm **out_comms);
+/* The same collectives between `world_size` communicators that share ONE device inside one
+ * process (RCCL refuses two ranks on a GPU): device-to-device copies and an accumulate kernel,
+ * ordered across the ranks' streams by HIP events.  Call the collectives from one host thread per
+ * rank (they rendezvous).  For single-GPU hosts and for testing the sharded render end to end. */
+int ptw_comm_create_loopback(int32_t world_size, int32_t device, ptw_comm **out_comms);
+/* Gives up on a communicator whose peer will never arrive (a rank failed before its collective):
+ * releases every rank that waits in a collective of it - ncclCommAbort / wakes the loopback
+ * rendezvous - after which the only valid call is ptw_comm_destroy. */
+int ptw_comm_abort(ptw_comm *comm);
 void ptw_comm_destroy(ptw_comm *comm);
 /* `output += pass` for whole framebuffers (ArrayOutput::operator+=, ArrayOutput.cpp:48-56):
  * the fp64 sums (npix * 3) and the u32 counts (npix) of every rank are summed into rank `root`'s

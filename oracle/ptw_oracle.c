@@ -544,6 +544,9 @@ static int render_pass_impl(const ptw_scene_view *scene, const ptw_camera *camer
   int row_begin = 0, row_end = height, row_stride = 1, row_phase = 0;
   if (rp->rng_policy == PTW_RNG_SEQUENTIAL) {
     oracle_mt_seed(&rng.mt, pass_seed);
+    /* include/ptw.h: under SEQUENTIAL only a PREFIX [0, row_end) of the rows can be rendered on
+     * its own - it is what the full pass produces for those rows */
+    if (rp->row_begin == 0 && rp->row_end > 0 && rp->row_end < height) row_end = rp->row_end;
   } else {
     /* the row window of include/ptw.h: (0,0) = all rows, begin == end != 0 = empty shard */
     if (rp->row_begin != 0 || rp->row_end != 0) {
@@ -647,6 +650,8 @@ int oracle_render(const ptw_scene_view *scene, const ptw_camera *camera,
       row_stride = params->row_stride;
       row_phase = params->row_phase;
     }
+  } else if (params->row_begin == 0 && params->row_end > 0 && params->row_end < params->height) {
+    row_end = params->row_end; /* SEQUENTIAL: a prefix of the rows (see render_pass_impl) */
   }
   /* output += pass (ArrayOutput::operator+=, ArrayOutput.cpp:48-56), in pass order */
   for (int pass = 0; pass < spp; ++pass) {

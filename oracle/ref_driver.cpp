@@ -94,11 +94,14 @@ RenderParams toParams(const ptw_render_params &p) {
 }
 
 // One pass exactly as the worker lambda does it (src/dod/Scene.cpp:209-219).
+// `rowEnd` < height: only the PREFIX [0, rowEnd) of the frame's rows (a pass walks the pixels in
+// row-major order, so the prefix is exactly what the full pass produces for those rows; bench.py's
+// bounded parity legs on the large frames).
 void renderPass(const dod::Scene &scene, const Camera &camera, const RenderParams &rp, int pass,
-                int firstPass, double *radiance_out, uint32_t *words_out) {
+                int firstPass, double *radiance_out, uint32_t *words_out, int rowEnd) {
   std::mt19937 rng(rp.seed + firstPass + pass);
   std::mt19937 shadow = rng;
-  for (auto y = 0; y < rp.height; ++y) {
+  for (auto y = 0; y < rowEnd; ++y) {
     for (auto x = 0; x < rp.width; ++x) {
       auto ray = camera.randomRay(x, y, rng);
       Vec3 c = scene.radiance(rng, ray, 0, rp);
@@ -197,7 +200,8 @@ REF_API void ref_render_pass(void *s, const CamDesc *d, const ptw_render_params 
   auto &scene = static_cast<RefScene *>(s)->scene;
   RenderParams rp = toParams(*p);
   Camera camera = makeCamera(*d, rp.width, rp.height);
-  renderPass(scene, camera, rp, pass, p->first_pass, radiance_out, words_out);
+  const int rowEnd = (p->row_begin == 0 && p->row_end > 0 && p->row_end < rp.height) ? p->row_end : rp.height;
+  renderPass(scene, camera, rp, pass, p->first_pass, radiance_out, words_out, rowEnd);
 }
 
 // All passes on `threads` threads (one whole-frame pass per thread at a time, like the

@@ -160,6 +160,8 @@ _sig("ptw_render_ex", C.c_int, C.POINTER(SceneView), C.POINTER(Camera), C.POINTE
 _sig("ptw_comm_unique_id", C.c_int, C.c_void_p)
 _sig("ptw_comm_create", C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p))
 _sig("ptw_comm_create_all", C.c_int, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p))
+_sig("ptw_comm_create_loopback", C.c_int, C.c_int32, C.c_int32, C.POINTER(C.c_void_p))
+_sig("ptw_comm_abort", C.c_int, C.c_void_p)
 _sig("ptw_comm_destroy", None, C.c_void_p)
 _sig("ptw_comm_reduce_framebuffer", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
      C.c_int32, C.c_void_p)
@@ -321,7 +323,7 @@ def render(scene: Scene, camera: Camera, params: RenderParams, rgb_sum=None, cou
         return rgb_sum, counts
     opt = RenderOptions()
     opt.num_devices = int(num_devices)
-    opt.share_device = int(bool(share_device))
+    opt.share_device = int(share_device)  # 0 | 1 (True): shards one after another | 2: threads + loopback collective
     opt.min_updates = int(min_updates)
     if cb:
         opt.progress = cb
@@ -354,6 +356,17 @@ class Comm:
         h = C.c_void_p()
         _check(lib.ptw_comm_create(buf, world_size, rank, device, C.byref(h)))
         return cls(h)
+
+    @classmethod
+    def create_loopback(cls, world_size: int, device: int = 0) -> "list[Comm]":
+        """`world_size` communicators on ONE device inside this process (ptw_comm_create_loopback);
+        call their collectives from one host thread per rank."""
+        arr = (C.c_void_p * world_size)()
+        _check(lib.ptw_comm_create_loopback(world_size, device, arr))
+        return [cls(C.c_void_p(arr[i])) for i in range(world_size)]
+
+    def abort(self):
+        _check(lib.ptw_comm_abort(self._h))
 
     def close(self):
         if self._h:

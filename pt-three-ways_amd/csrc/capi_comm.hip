@@ -12,6 +12,15 @@
 // librccl is bound at first use (dlopen of the soname): a process that already carries an RCCL
 // (PyTorch-ROCm bundles one as librccl.so.1) keeps a single copy, and the library still loads on
 // hosts without a GPU.
+//
+// Two transports sit under the same entry points (and under the same packing / slot arithmetic /
+// unpacking code of the gather):
+//   RCCL      ptw_comm_create / ptw_comm_create_all: one communicator per GPU, xGMI;
+//   loopback  ptw_comm_create_loopback: `world` communicators that share ONE device and meet in
+//             host memory of one process - device-to-device copies and an accumulate kernel ordered
+//             by HIP events across the ranks' streams.  RCCL refuses two ranks on one GPU; this is
+//             how a host with a single GPU (and the tests) run the sharded render end to end:
+//             ptw_render_ex(num_devices = N, share_device = 2).
 #include "capi_common.h"
 
 #include <hip/hip_runtime.h>
@@ -19,6 +28,7 @@
 
 #include <dlfcn.h>
 
+#include <condition_variable>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -34,6 +44,7 @@ struct Rccl {
   decltype(&ncclCommInitRank) commInitRank = nullptr;
   decltype(&ncclCommInitAll) commInitAll = nullptr;
   decltype(&ncclCommDestroy) commDestroy = nullptr;
+  decltype(&ncclCommAbort) commAbort = nullptr;
   decltype(&ncclGetErrorString) getErrorString = nullptr;
   decltype(&ncclReduce) reduce = nullptr;
   decltype(&ncclSend) send = nullptr;
@@ -63,6 +74,7 @@ const Rccl &rccl() {
     sym(api.commInitRank, "ncclCommInitRank");
     sym(api.commInitAll, "ncclCommInitAll");
     sym(api.commDestroy, "ncclCommDestroy");
+    sym(api.commAbort, "ncclCommAbort");
     sym(api.getErrorString, "ncclGetErrorString");
     sym(api.reduce, "ncclReduce");
     sym(api.send, "ncclSend");
@@ -85,13 +97,57 @@ void checkHip(hipError_t e, const char *what) {
 
 static_assert(PTW_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
 
+// ---- loopback transport ---------------------------------------------------------------------
+// A message is a device buffer plus the event after which its contents are final on the sender's
+// stream.  The receiver makes its own stream wait for that event, consumes the buffer (copy or
+// accumulate), records a `consumed` event and hands it back; the sender's stream waits for it
+// before it may touch the buffer again.  The host threads of the ranks rendezvous on a mutex +
+// condition variable; abort() wakes every waiter with an error.
+struct LoopMessage {
+  const void *ptr = nullptr;
+  size_t bytes = 0;
+  hipEvent_t ready = nullptr;    // owned by the sender
+  hipEvent_t consumed = nullptr; // owned by the receiver
+  int state = 0;                 // 0 empty, 1 posted, 2 consumed
+};
+
+struct LoopbackHub {
+  std::mutex m;
+  std::condition_variable cv;
+  int world = 0;
+  bool aborted = false;
+  std::vector<LoopMessage> box; // [src * world + dst] * 2 + channel (two messages per pair in flight)
+  explicit LoopbackHub(int w) : world(w), box(static_cast<size_t>(w) * w * 2) {}
+  LoopMessage &at(int src, int dst, int channel) {
+    return box[(static_cast<size_t>(src) * world + dst) * 2 + channel];
+  }
+  void abort() {
+    std::lock_guard<std::mutex> lock(m);
+    aborted = true;
+    cv.notify_all();
+  }
+};
+
+__global__ void loopAccumulateF64(double *__restrict__ dst, const double *__restrict__ src, size_t n) {
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<size_t>(gridDim.x) * blockDim.x)
+    dst[i] += src[i];
+}
+__global__ void loopAccumulateU32(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t n) {
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<size_t>(gridDim.x) * blockDim.x)
+    dst[i] += src[i];
+}
+
 } // namespace
 } // namespace ptw
 
 using namespace ptw;
 
 struct ptw_comm {
-  ncclComm_t comm = nullptr;
+  ncclComm_t comm = nullptr;          // RCCL transport
+  std::shared_ptr<LoopbackHub> hub;   // loopback transport (comm == nullptr)
+  std::vector<hipEvent_t> events;     // loopback: events this rank created (destroyed with it)
   int world = 1, rank = 0, device = 0;
   // packed rows of the gather: [rows][width][3] doubles then [rows][width] u32, per rank slot
   void *pack = nullptr;
@@ -99,7 +155,61 @@ struct ptw_comm {
   ~ptw_comm() {
     (void)hipSetDevice(device);
     if (pack) (void)hipFree(pack);
+    for (hipEvent_t e : events) (void)hipEventDestroy(e);
     if (comm) (void)rccl().commDestroy(comm);
+  }
+  hipEvent_t newEvent() {
+    hipEvent_t e = nullptr;
+    checkHip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+    events.push_back(e);
+    return e;
+  }
+  // ---- the two point-to-point primitives the collectives are written in -----------------------
+  // (RCCL: ncclSend / ncclRecv inside the caller's group; loopback: see LoopbackHub)
+  void loopSend(const void *ptr, size_t bytes, int dst, int channel, hipStream_t stream) {
+    const hipEvent_t ready = newEvent();
+    checkHip(hipEventRecord(ready, stream), "hipEventRecord");
+    hipEvent_t consumed = nullptr;
+    {
+      std::unique_lock<std::mutex> lock(hub->m);
+      LoopMessage &msg = hub->at(rank, dst, channel);
+      hub->cv.wait(lock, [&] { return hub->aborted || msg.state == 0; });
+      if (hub->aborted) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
+      msg.ptr = ptr, msg.bytes = bytes, msg.ready = ready, msg.state = 1;
+      hub->cv.notify_all();
+      hub->cv.wait(lock, [&] { return hub->aborted || msg.state == 2; });
+      if (hub->aborted) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
+      consumed = msg.consumed;
+      msg = LoopMessage();
+      hub->cv.notify_all();
+    }
+    // the buffer may be reused on this stream only after the receiver has consumed it
+    checkHip(hipStreamWaitEvent(stream, consumed, 0), "hipStreamWaitEvent");
+  }
+  // Waits for the message, lets `consume(ptr, bytes)` enqueue its work on `stream`.
+  template <typename Consume>
+  void loopRecv(int src, int channel, size_t expectBytes, hipStream_t stream, Consume &&consume) {
+    LoopMessage got;
+    {
+      std::unique_lock<std::mutex> lock(hub->m);
+      LoopMessage &msg = hub->at(src, rank, channel);
+      hub->cv.wait(lock, [&] { return hub->aborted || msg.state == 1; });
+      if (hub->aborted) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
+      got = msg;
+    }
+    if (got.bytes != expectBytes)
+      throw DeviceError(PTW_ERR_SIZE_MISMATCH, "loopback message of " + std::to_string(got.bytes) +
+                                                   " bytes where " + std::to_string(expectBytes) + " were expected");
+    checkHip(hipStreamWaitEvent(stream, got.ready, 0), "hipStreamWaitEvent");
+    consume(got.ptr, got.bytes);
+    const hipEvent_t consumed = newEvent();
+    checkHip(hipEventRecord(consumed, stream), "hipEventRecord");
+    {
+      std::lock_guard<std::mutex> lock(hub->m);
+      LoopMessage &msg = hub->at(src, rank, channel);
+      msg.consumed = consumed, msg.state = 2;
+      hub->cv.notify_all();
+    }
   }
   void reservePack(size_t bytes) {
     if (bytes <= packBytes) return;
@@ -167,6 +277,38 @@ int ptw_comm_create_all(int32_t num_devices, const int32_t *devices, ptw_comm **
   PTW_GUARD_END
 }
 
+int ptw_comm_create_loopback(int32_t world_size, int32_t device, ptw_comm **out_comms) {
+  if (!out_comms || world_size < 1) return invalid("world_size / out_comms");
+  PTW_GUARD_BEGIN
+  checkHip(hipSetDevice(device), "hipSetDevice");
+  auto hub = std::make_shared<LoopbackHub>(world_size);
+  for (int i = 0; i < world_size; ++i) {
+    auto *c = new ptw_comm;
+    c->hub = hub;
+    c->world = world_size;
+    c->rank = i;
+    c->device = device;
+    out_comms[i] = c;
+  }
+  return PTW_OK;
+  PTW_GUARD_END
+}
+
+int ptw_comm_abort(ptw_comm *comm) {
+  if (!comm) return invalid("comm");
+  PTW_GUARD_BEGIN
+  if (comm->hub) {
+    comm->hub->abort();
+  } else if (comm->comm) {
+    // ncclCommAbort frees the communicator: kernels of it that wait for a peer on the device end
+    const ncclComm_t c = comm->comm;
+    comm->comm = nullptr;
+    checkNccl(rccl().commAbort(c), "ncclCommAbort");
+  }
+  return PTW_OK;
+  PTW_GUARD_END
+}
+
 void ptw_comm_destroy(ptw_comm *comm) { delete comm; }
 
 int ptw_comm_reduce_framebuffer(ptw_comm *comm, void *d_rgb_sum, void *d_counts, uint64_t npix,
@@ -174,9 +316,33 @@ int ptw_comm_reduce_framebuffer(ptw_comm *comm, void *d_rgb_sum, void *d_counts,
   if (!comm || !d_rgb_sum || !d_counts) return invalid("null pointer");
   if (root < 0 || root >= comm->world) return invalid("root");
   PTW_GUARD_BEGIN
-  const Rccl &api = rccl();
   checkHip(hipSetDevice(comm->device), "hipSetDevice");
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  if (comm->hub) {
+    // loopback: the root adds the other ranks' buffers to its own, in rank order
+    if (comm->world == 1) return PTW_OK;
+    if (comm->rank != root) {
+      comm->loopSend(d_rgb_sum, npix * 3 * sizeof(double), root, 0, stream);
+      comm->loopSend(d_counts, npix * sizeof(uint32_t), root, 1, stream);
+      return PTW_OK;
+    }
+    for (int r = 0; r < comm->world; ++r) {
+      if (r == root) continue;
+      comm->loopRecv(r, 0, npix * 3 * sizeof(double), stream, [&](const void *src, size_t) {
+        hipLaunchKernelGGL(loopAccumulateF64, dim3(1024), dim3(256), 0, stream, static_cast<double *>(d_rgb_sum),
+                           static_cast<const double *>(src), static_cast<size_t>(npix) * 3);
+        checkHip(hipGetLastError(), "accumulate launch");
+      });
+      comm->loopRecv(r, 1, npix * sizeof(uint32_t), stream, [&](const void *src, size_t) {
+        hipLaunchKernelGGL(loopAccumulateU32, dim3(1024), dim3(256), 0, stream, static_cast<uint32_t *>(d_counts),
+                           static_cast<const uint32_t *>(src), static_cast<size_t>(npix));
+        checkHip(hipGetLastError(), "accumulate launch");
+      });
+    }
+    return PTW_OK;
+  }
+  if (!comm->comm) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
+  const Rccl &api = rccl();
   // one group: both reductions are launched together
   checkNccl(api.groupStart(), "ncclGroupStart");
   checkNccl(api.reduce(d_rgb_sum, d_rgb_sum, npix * 3, ncclDouble, ncclSum, root, comm->comm, stream),
@@ -194,11 +360,13 @@ int ptw_comm_gather_rows(ptw_comm *comm, void *d_rgb_sum, void *d_counts, int32_
   if (width <= 0 || height <= 0) return invalid("width / height");
   if (root < 0 || root >= comm->world) return invalid("root");
   PTW_GUARD_BEGIN
-  const Rccl &api = rccl();
   checkHip(hipSetDevice(comm->device), "hipSetDevice");
   hipStream_t stream = static_cast<hipStream_t>(hip_stream);
   const int world = comm->world, rank = comm->rank;
   if (world == 1) return PTW_OK;
+  const bool loop = static_cast<bool>(comm->hub);
+  if (!loop && !comm->comm) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
+  const Rccl *api = loop ? nullptr : &rccl();
   const size_t w = static_cast<size_t>(width);
   const size_t rgbRow = w * 3 * sizeof(double), cntRow = w * sizeof(uint32_t);
   auto rowsOf = [&](int r) { return static_cast<size_t>(height > r ? (height - r + world - 1) / world : 0); };
@@ -218,25 +386,45 @@ int ptw_comm_gather_rows(ptw_comm *comm, void *d_rgb_sum, void *d_counts, int32_
       checkHip(hipMemcpy2DAsync(packCnt, cntRow, cnt + rank * cntRow, world * cntRow, cntRow, rows,
                                 hipMemcpyDeviceToDevice, stream), "pack counts");
     }
-    checkNccl(api.groupStart(), "ncclGroupStart");
-    if (rows) {
-      checkNccl(api.send(packRgb, rows * w * 3, ncclDouble, root, comm->comm, stream), "ncclSend(rgb)");
-      checkNccl(api.send(packCnt, rows * w, ncclUint32, root, comm->comm, stream), "ncclSend(counts)");
+    if (loop) {
+      if (rows) {
+        comm->loopSend(packRgb, rows * rgbRow, root, 0, stream);
+        comm->loopSend(packCnt, rows * cntRow, root, 1, stream);
+      }
+      return PTW_OK;
     }
-    checkNccl(api.groupEnd(), "ncclGroupEnd");
+    checkNccl(api->groupStart(), "ncclGroupStart");
+    if (rows) {
+      checkNccl(api->send(packRgb, rows * w * 3, ncclDouble, root, comm->comm, stream), "ncclSend(rgb)");
+      checkNccl(api->send(packCnt, rows * w, ncclUint32, root, comm->comm, stream), "ncclSend(counts)");
+    }
+    checkNccl(api->groupEnd(), "ncclGroupEnd");
     return PTW_OK;
   }
   // root: receive every other rank's packed rows, then scatter them into their image rows
   comm->reservePack(static_cast<size_t>(world) * (slotRgb + slotCnt));
   char *base = static_cast<char *>(comm->pack);
-  checkNccl(api.groupStart(), "ncclGroupStart");
-  for (int r = 0; r < world; ++r) {
-    if (r == root || rowsOf(r) == 0) continue;
-    char *slot = base + static_cast<size_t>(r) * (slotRgb + slotCnt);
-    checkNccl(api.recv(slot, rowsOf(r) * w * 3, ncclDouble, r, comm->comm, stream), "ncclRecv(rgb)");
-    checkNccl(api.recv(slot + slotRgb, rowsOf(r) * w, ncclUint32, r, comm->comm, stream), "ncclRecv(counts)");
+  if (loop) {
+    for (int r = 0; r < world; ++r) {
+      if (r == root || rowsOf(r) == 0) continue;
+      char *slot = base + static_cast<size_t>(r) * (slotRgb + slotCnt);
+      comm->loopRecv(r, 0, rowsOf(r) * rgbRow, stream, [&](const void *src, size_t bytes) {
+        checkHip(hipMemcpyAsync(slot, src, bytes, hipMemcpyDeviceToDevice, stream), "recv rgb");
+      });
+      comm->loopRecv(r, 1, rowsOf(r) * cntRow, stream, [&](const void *src, size_t bytes) {
+        checkHip(hipMemcpyAsync(slot + slotRgb, src, bytes, hipMemcpyDeviceToDevice, stream), "recv counts");
+      });
+    }
+  } else {
+    checkNccl(api->groupStart(), "ncclGroupStart");
+    for (int r = 0; r < world; ++r) {
+      if (r == root || rowsOf(r) == 0) continue;
+      char *slot = base + static_cast<size_t>(r) * (slotRgb + slotCnt);
+      checkNccl(api->recv(slot, rowsOf(r) * w * 3, ncclDouble, r, comm->comm, stream), "ncclRecv(rgb)");
+      checkNccl(api->recv(slot + slotRgb, rowsOf(r) * w, ncclUint32, r, comm->comm, stream), "ncclRecv(counts)");
+    }
+    checkNccl(api->groupEnd(), "ncclGroupEnd");
   }
-  checkNccl(api.groupEnd(), "ncclGroupEnd");
   for (int r = 0; r < world; ++r) {
     if (r == root || rowsOf(r) == 0) continue;
     char *slot = base + static_cast<size_t>(r) * (slotRgb + slotCnt);

@@ -5,10 +5,15 @@
 #include "capi_common.h"
 #include "ptw_kernels.h"
 
+#ifndef PTW_EXPERIMENTS
+#define PTW_EXPERIMENTS 0
+#endif
+
 #include "../host/bvh.h"
 #include "../host/precompute.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -89,7 +94,8 @@ struct ptw_context {
   // context, see include/ptw.h).
   std::vector<uint32_t> hostSeedStates, hostPos;
   hipEvent_t uploadsDone = nullptr; // recorded after a render's uploads: the host vectors are free again
-  const char *traceKernel = ""; // variant name of the last trace launch
+  char traceKernel[64] = ""; // variant name of the last trace launch (a copy: the launcher's
+                             // string lives in thread-local storage of the launching thread)
 
   bool statsEnabled = false;
   struct Timed {
@@ -244,18 +250,32 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   t.rowStride = rows.stride;
   const uint32_t pixTotal = static_cast<uint32_t>(rows.count) * static_cast<uint32_t>(p.width);
 
-  // Band size: the staging buffer holds npass x bandPix x 3 doubles.
-  uint64_t bandPix = ctx.stageBudgetBytes / (static_cast<uint64_t>(npass) * 24);
+  // Band size: the staging buffer holds npass x bandPix x 3 doubles.  The budget is clamped to
+  // half of what the device has free right now (plus what this context already holds for staging):
+  // a frame that does not fit is cut into more bands instead of failing in hipMalloc.
+  size_t budget = ctx.stageBudgetBytes;
+  {
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+      const size_t held = ctx.stage.capacity * sizeof(double);
+      budget = std::min(budget, std::max<size_t>((freeB + held) / 2, size_t(1) << 20));
+    }
+  }
+  uint64_t bandPix = budget / (static_cast<uint64_t>(npass) * 24);
   if (minBands > 1) bandPix = std::min<uint64_t>(bandPix, (pixTotal + minBands - 1) / minBands);
   bandPix = std::max<uint64_t>(bandPix, 64);
   bandPix = std::min<uint64_t>(bandPix, pixTotal);
-  // The wide sequential kernel picks its speculation candidates per band from the statistics of
+  // (experiments build) The wide sequential kernel picks its speculation candidates per band from the statistics of
   // the band before: give it a short first band to measure on and at least eight bands, so that
   // the set follows the image from top to bottom.
-  static const char *wideEnv = std::getenv("PTW_SEQ_WIDE");
-  static const char *spec8Env = std::getenv("PTW_SEQ_SPEC8");
+#if PTW_EXPERIMENTS
+  const char *wideEnv = std::getenv("PTW_SEQ_WIDE");
+  const char *spec8Env = std::getenv("PTW_SEQ_SPEC8");
   const bool adaptive = sequential && pixTotal >= 16384 && ctx.ntri <= 64 &&
                         ((wideEnv && wideEnv[0] == '1' && wideKernelApplies(t)) || (spec8Env && spec8Env[0] == '1'));
+#else
+  const bool adaptive = false;
+#endif
   if (adaptive) bandPix = std::min<uint64_t>(bandPix, (pixTotal + 7) / 8);
   // equal bands (the last one is not a sliver)
   const uint64_t nBands = (pixTotal + bandPix - 1) / bandPix;
@@ -300,15 +320,17 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   ctx.sampleQueue.reserve(1);
   b.sampleQueue = ctx.sampleQueue.ptr;
   b.specState = sequential ? ctx.specState.ptr : nullptr;
+#if PTW_EXPERIMENTS
   if (sequential && !ctx.countHist.ptr) {
     ctx.countHist.reserve(8);
     check(hipMemsetAsync(ctx.countHist.ptr, 0, 8 * sizeof(unsigned long long), stream), "memset");
   }
+  ctx.wideCands.reserve(wideCandidateBytes());
+#endif
   b.bvhNodes = ctx.bvhNodes.ptr;
   b.bvhLeafGeom = ctx.bvhLeafGeom.ptr;
   b.bvhLeafIndex = ctx.bvhLeafIndex.ptr;
-  b.countHist = ctx.countHist.ptr;
-  ctx.wideCands.reserve(wideCandidateBytes());
+  b.countHist = ctx.countHist.ptr; // (experiments only: null in the shipped library)
   b.wideCands = ctx.wideCands.ptr;
 
   auto timedLaunch = [&](bool trace, auto &&launch) {
@@ -333,10 +355,12 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
     if (begin == 0 && calibrationPix) t.pixCount = std::min(t.pixCount, calibrationPix);
     begin += t.pixCount;
     t.firstBand = t.pixBegin == 0;
+    const char *variant = "";
     if (sequential)
-      timedLaunch(true, [&] { return launchTraceSequential(t, b, stream, &ctx.traceKernel); });
+      timedLaunch(true, [&] { return launchTraceSequential(t, b, stream, &variant); });
     else
-      timedLaunch(true, [&] { return launchTracePerPixel(t, b, stream, &ctx.traceKernel); });
+      timedLaunch(true, [&] { return launchTracePerPixel(t, b, stream, &variant); });
+    std::snprintf(ctx.traceKernel, sizeof ctx.traceKernel, "%s", variant ? variant : "");
     timedLaunch(false, [&] { return launchResolve(t, ctx.stage.ptr, dRgb, dCounts, stream); });
     done += static_cast<uint64_t>(t.pixCount) * npass;
     ctx.statSamples += static_cast<uint64_t>(t.pixCount) * npass;
@@ -641,8 +665,8 @@ void renderMulti(const ptw_scene_view &scene, const ptw_camera &camera,
     }
   }
 
-  if (opt.share_device) {
-    // Test hook for 1-GPU boxes: the same shards, one after another, accumulated on the device.
+  if (opt.share_device == 1) {
+    // Hook for 1-GPU boxes: the same shards, one after another, accumulated on the device.
     DeviceShard &sh = shards[0];
     ptw_context *raw = nullptr;
     if (ptw_context_create(sh.device, &raw) != PTW_OK) throw DeviceError(PTW_ERR_NO_DEVICE, ptw_last_error());
@@ -654,75 +678,138 @@ void renderMulti(const ptw_scene_view &scene, const ptw_camera &camera,
       enqueueRender(*sh.ctx, camera, shards[g].params, sh.rgb.ptr, sh.counts.ptr, nullptr, nullptr, 0,
                     [](const TraceParams &, uint64_t, uint64_t) { return false; });
       check(hipStreamSynchronize(nullptr), "render");
-      if (opt.progress) opt.progress(opt.progress_user, static_cast<uint64_t>(g + 1), static_cast<uint64_t>(n));
+      if (opt.progress && opt.progress(opt.progress_user, static_cast<uint64_t>(g + 1), static_cast<uint64_t>(n)) != 0)
+        throw std::invalid_argument("cancelled by the callback");
     }
     check(hipMemcpy(rgbSum, sh.rgb.ptr, npix * 3 * sizeof(double), hipMemcpyDeviceToHost), "D2H");
     check(hipMemcpy(counts, sh.counts.ptr, npix * sizeof(uint32_t), hipMemcpyDeviceToHost), "D2H");
     return;
   }
 
+  // One communicator per shard: RCCL over the devices, or - share_device == 2, every shard on
+  // params->device - the in-process loopback transport (RCCL refuses two ranks on one GPU): the same
+  // host threads, contexts, streams and collective entry points as the N-GPU render.
   std::vector<ptw_comm *> comms(static_cast<size_t>(n), nullptr);
-  if (ptw_comm_create_all(n, devices.data(), comms.data()) != PTW_OK)
-    throw DeviceError(PTW_ERR_HIP, ptw_last_error());
+  const int commRc = opt.share_device ? ptw_comm_create_loopback(n, params.device, comms.data())
+                                      : ptw_comm_create_all(n, devices.data(), comms.data());
+  if (commRc != PTW_OK) throw DeviceError(PTW_ERR_HIP, ptw_last_error());
   struct CommGuard {
     std::vector<ptw_comm *> &c;
     ~CommGuard() {
       for (auto *x : c) ptw_comm_destroy(x);
     }
   } commGuard{comms};
+  auto abortAll = [&] {
+    for (auto *c : comms) (void)ptw_comm_abort(c);
+  };
+  // Failure injection for the tests (a shard that fails must end the render with an error on every
+  // path, never leave its peers waiting in a collective): PTW_TEST_FAIL_SHARD=g fails shard g's
+  // set-up, PTW_TEST_FAIL_COLLECTIVE=g fails shard g's collective call.
+  auto envShard = [](const char *name) {
+    const char *v = std::getenv(name);
+    return v && *v ? std::atoi(v) : -1;
+  };
+  const int failSetup = envShard("PTW_TEST_FAIL_SHARD"), failCollective = envShard("PTW_TEST_FAIL_COLLECTIVE");
 
-  // One host thread per device: context + scene upload, render, then the one collective.  A
-  // rank that failed still enters the collective (with whatever its buffers hold) so that the
-  // others are not left waiting; the error is reported afterwards.
-  std::vector<std::thread> threads;
-  for (int g = 0; g < n; ++g)
-    threads.emplace_back([&, g] {
-      DeviceShard &sh = shards[g];
-      guarded(sh, [&] {
-        ptw_context *raw = nullptr;
-        if (ptw_context_create(sh.device, &raw) != PTW_OK) throw DeviceError(PTW_ERR_NO_DEVICE, ptw_last_error());
-        sh.ctx.reset(raw);
-        if (int rc = ptw_context_set_scene(sh.ctx.get(), &scene); rc != PTW_OK) throw DeviceError(rc, ptw_last_error());
-        check(hipStreamCreateWithFlags(&sh.stream, hipStreamNonBlocking), "hipStreamCreate");
-        sh.rgb.reserve(npix * 3);
-        sh.counts.reserve(npix);
-        // The caller's running sums (ArrayOutput +=): under the pass sharding they live on the first
-        // device and the reduce adds the others' passes; under the row sharding every device adds its
-        // rows to its own copy and the gather brings those rows - old content included - to the root.
-        if (g == 0 || !sequential) {
-          sh.rgb.upload(rgbSum, npix * 3, sh.stream);
-          sh.counts.upload(counts, npix, sh.stream);
-        } else {
-          check(hipMemsetAsync(sh.rgb.ptr, 0, npix * 3 * sizeof(double), sh.stream), "memset");
-          check(hipMemsetAsync(sh.counts.ptr, 0, npix * sizeof(uint32_t), sh.stream), "memset");
-        }
-        enqueueRender(*sh.ctx, camera, sh.params, sh.rgb.ptr, sh.counts.ptr, nullptr, sh.stream,
-                      g == 0 && opt.progress ? 20 : 0,
-                      [&](const TraceParams &, uint64_t done, uint64_t totalSamples) {
-                        if (g != 0 || !opt.progress) return false;
-                        check(hipStreamSynchronize(sh.stream), "band");
-                        (void)opt.progress(opt.progress_user, done * n, totalSamples * n);
-                        return false;
-                      });
+  // ---- phase 1, one host thread per device: context + scene upload, the render, and its
+  // completion.  No collective yet: a shard that fails here has no peer waiting for it. ----
+  std::atomic<bool> cancelled{false};
+  {
+    std::vector<std::thread> threads;
+    for (int g = 0; g < n; ++g)
+      threads.emplace_back([&, g] {
+        DeviceShard &sh = shards[g];
+        guarded(sh, [&] {
+          if (g == failSetup) throw DeviceError(PTW_ERR_HIP, "injected failure (PTW_TEST_FAIL_SHARD)");
+          ptw_context *raw = nullptr;
+          if (ptw_context_create(sh.device, &raw) != PTW_OK) throw DeviceError(PTW_ERR_NO_DEVICE, ptw_last_error());
+          sh.ctx.reset(raw);
+          if (int rc = ptw_context_set_scene(sh.ctx.get(), &scene); rc != PTW_OK) throw DeviceError(rc, ptw_last_error());
+          check(hipStreamCreateWithFlags(&sh.stream, hipStreamNonBlocking), "hipStreamCreate");
+          sh.rgb.reserve(npix * 3);
+          sh.counts.reserve(npix);
+          // The caller's running sums (ArrayOutput +=): under the pass sharding they live on the first
+          // device and the reduce adds the others' passes; under the row sharding every device adds its
+          // rows to its own copy and the gather brings those rows - old content included - to the root.
+          if (g == 0 || !sequential) {
+            sh.rgb.upload(rgbSum, npix * 3, sh.stream);
+            sh.counts.upload(counts, npix, sh.stream);
+          } else {
+            check(hipMemsetAsync(sh.rgb.ptr, 0, npix * 3 * sizeof(double), sh.stream), "memset");
+            check(hipMemsetAsync(sh.counts.ptr, 0, npix * sizeof(uint32_t), sh.stream), "memset");
+          }
+          enqueueRender(*sh.ctx, camera, sh.params, sh.rgb.ptr, sh.counts.ptr, nullptr, sh.stream,
+                        g == 0 && opt.progress ? 20 : 0,
+                        [&](const TraceParams &, uint64_t done, uint64_t totalSamples) {
+                          if (g == 0 && opt.progress) {
+                            check(hipStreamSynchronize(sh.stream), "band");
+                            if (opt.progress(opt.progress_user, done * n, totalSamples * n) != 0) cancelled = true;
+                          }
+                          return cancelled.load(); // every shard stops at its next band
+                        });
+          check(hipStreamSynchronize(sh.stream), "render");
+        });
       });
-      if (sh.ctx && sh.stream && sh.rgb.ptr && sh.counts.ptr) {
+    for (auto &t : threads) t.join();
+  }
+  auto firstFailure = [&]() -> const DeviceShard * {
+    for (const DeviceShard &sh : shards)
+      if (sh.status != PTW_OK) return &sh;
+    return nullptr;
+  };
+  if (const DeviceShard *bad = firstFailure()) {
+    abortAll();
+    throw DeviceError(bad->status, "device " + std::to_string(bad->device) + ": " + bad->error);
+  }
+  if (cancelled) {
+    abortAll();
+    throw std::invalid_argument("cancelled by the callback");
+  }
+
+  // ---- phase 2: the one collective, entered by every shard (all of them are healthy).  A shard
+  // whose call fails aborts its communicator, which releases the peers (loopback: the host
+  // rendezvous; RCCL: after the join below every communicator is aborted, which ends the kernels
+  // that wait for the missing peer on the device). ----
+  {
+    std::vector<std::thread> threads;
+    for (int g = 0; g < n; ++g)
+      threads.emplace_back([&, g] {
+        DeviceShard &sh = shards[g];
         int rc;
-        if (sequential)
-          rc = ptw_comm_reduce_framebuffer(comms[g], sh.rgb.ptr, sh.counts.ptr, npix, 0, sh.stream);
-        else
-          rc = ptw_comm_gather_rows(comms[g], sh.rgb.ptr, sh.counts.ptr, params.width, params.height, 0,
-                                    sh.stream);
-        if (rc != PTW_OK && sh.status == PTW_OK) sh.status = rc, sh.error = ptw_last_error();
-        (void)hipSetDevice(sh.device);
-        if (hipStreamSynchronize(sh.stream) != hipSuccess && sh.status == PTW_OK)
-          sh.status = PTW_ERR_HIP, sh.error = "stream synchronise failed after the collective";
-      } else if (sh.status == PTW_OK) {
-        sh.status = PTW_ERR_HIP, sh.error = "device shard was not set up";
+        if (g == failCollective) {
+          rc = PTW_ERR_HIP;
+          sh.error = "injected failure (PTW_TEST_FAIL_COLLECTIVE)";
+        } else {
+          if (sequential)
+            rc = ptw_comm_reduce_framebuffer(comms[g], sh.rgb.ptr, sh.counts.ptr, npix, 0, sh.stream);
+          else
+            rc = ptw_comm_gather_rows(comms[g], sh.rgb.ptr, sh.counts.ptr, params.width, params.height, 0,
+                                      sh.stream);
+          if (rc != PTW_OK) sh.error = ptw_last_error();
+        }
+        if (rc != PTW_OK) {
+          sh.status = rc;
+          (void)ptw_comm_abort(comms[g]);
+        }
+      });
+    for (auto &t : threads) t.join();
+  }
+  if (const DeviceShard *bad = firstFailure()) {
+    // report the shard that failed on its own, not a peer that was released by the abort
+    for (const DeviceShard &sh : shards)
+      if (sh.status != PTW_OK && sh.error.find("aborted") == std::string::npos) {
+        bad = &sh;
+        break;
       }
-    });
-  for (auto &t : threads) t.join();
-  for (const DeviceShard &sh : shards)
-    if (sh.status != PTW_OK) throw DeviceError(sh.status, "device " + std::to_string(sh.device) + ": " + sh.error);
+    const int status = bad->status;
+    const std::string message = "device " + std::to_string(bad->device) + ": " + bad->error;
+    abortAll();
+    throw DeviceError(status, message);
+  }
+  for (DeviceShard &sh : shards) {
+    check(hipSetDevice(sh.device), "hipSetDevice");
+    check(hipStreamSynchronize(sh.stream), "collective");
+  }
   check(hipSetDevice(shards[0].device), "hipSetDevice");
   check(hipMemcpy(rgbSum, shards[0].rgb.ptr, npix * 3 * sizeof(double), hipMemcpyDeviceToHost), "D2H");
   check(hipMemcpy(counts, shards[0].counts.ptr, npix * sizeof(uint32_t), hipMemcpyDeviceToHost), "D2H");

@@ -11,6 +11,13 @@ pytestmark = pytest.mark.gpu
 def run_cli(pkg, args, cwd, env=None):
     import os
     exe = pkg.LIB_PATH.parent / "pt_three_ways_hip"
+    if env and env.get("PTW_USE_EXPERIMENTS"):
+        # the experiments build (make experiments) has the same soname in its own directory; the CLI
+        # finds the shipped library through RUNPATH=$ORIGIN, which LD_LIBRARY_PATH precedes
+        exp_dir = pkg.LIB_PATH.parent / "experiments"
+        if not (exp_dir / "libptw_hip.so").exists():
+            pytest.skip("experiments library not built (make -C pt-three-ways_amd experiments)")
+        env = dict(env, LD_LIBRARY_PATH=str(exp_dir) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
     proc = subprocess.run([str(exe)] + args, cwd=cwd, capture_output=True, text=True, timeout=300,
                           env=dict(os.environ, **env) if env else None)
     assert proc.returncode == 0, proc.stdout + proc.stderr
@@ -60,18 +67,23 @@ def test_chunked_save_every_and_png_and_merge(pkg, tmp_path):
     ("cornell", []), ("single-sphere", ["--max-depth", "3"]), ("cornell", ["--first-bounce-u", "3", "--first-bounce-v", "5"]),
 ])
 def test_sequential_kernel_variants_write_identical_bytes(pkg, tmp_path, scene, extra):
-    """The wide speculative kernel (8 or 16 lanes per candidate, full or short candidate list), the
-    speculative four-wave kernel, the single-wave register-stack kernel and the plain single-wave
-    kernel are schedules of one computation: same .raw bytes.  A tiny staging budget makes every
-    pass park and resume its stream dozens of times."""
+    """The speculative four-wave kernel, the single-wave register-stack kernel and the plain
+    single-wave kernel are schedules of one computation: same .raw bytes.  A tiny staging budget makes
+    every pass park and resume its stream dozens of times.  The opt-in kernels of the experiments
+    build (wide: 8 or 16 lanes per candidate, full or short candidate list; eight tracing waves)
+    are held to the same bytes when that build is present."""
     from conftest import ROOT
     args = ["-w", "40", "-h", "28", "--spp", "5", "--seed", "11", "--scene", scene, "--raw", "--save-every", "0"] + extra
     variants = {"spec": {}, "reg": {"PTW_SEQ_SPEC": "0"}, "plain": {"PTW_SEQ_SPEC": "0", "PTW_SEQ_REG": "0"},
                 "spec_bands": {"PTW_STAGE_BUDGET_KB": "12"},
-                "spec8": {"PTW_SEQ_SPEC8": "1"}, "spec8_bands": {"PTW_SEQ_SPEC8": "1", "PTW_STAGE_BUDGET_KB": "12"},
-                "wide8": {"PTW_SEQ_WIDE": "1", "PTW_WIDE_G": "8"}, "wide16": {"PTW_SEQ_WIDE": "1", "PTW_WIDE_G": "16"},
-                "wide8_few": {"PTW_SEQ_WIDE": "1", "PTW_WIDE_CANDIDATES": "5"},
-                "wide_bands": {"PTW_SEQ_WIDE": "1", "PTW_STAGE_BUDGET_KB": "12"}}
+                }
+    exp = {"PTW_USE_EXPERIMENTS": "1"}
+    if (pkg.LIB_PATH.parent / "experiments" / "libptw_hip.so").exists() and not extra:
+        variants.update({
+            "spec8": dict(exp, PTW_SEQ_SPEC8="1"), "spec8_bands": dict(exp, PTW_SEQ_SPEC8="1", PTW_STAGE_BUDGET_KB="12"),
+            "wide8": dict(exp, PTW_SEQ_WIDE="1", PTW_WIDE_G="8"), "wide16": dict(exp, PTW_SEQ_WIDE="1", PTW_WIDE_G="16"),
+            "wide8_few": dict(exp, PTW_SEQ_WIDE="1", PTW_WIDE_CANDIDATES="5"),
+            "wide_bands": dict(exp, PTW_SEQ_WIDE="1", PTW_STAGE_BUDGET_KB="12")})
     blobs = {}
     for name, env in variants.items():
         run_cli(pkg, args + [str(tmp_path / f"{name}.raw")], ROOT, env=env)

@@ -1,0 +1,379 @@
+"""GPU: round-3 additions.
+
+* the two-master worker-wave kernels - the ones BASELINE cfg3 (suzanne, 512 spp) and cfg4 (ce, 1024
+  spp) actually run, `traceSequential<SLOTS, 6, lds|global, stack, 2 masters>` - compared DIRECTLY
+  with the oracle (fp64 sums to 1e-12, every sample's RNG word count exact) on triangle soups sized
+  to reach all eleven instantiations, with odd and even pass counts, parked streams, and once through
+  the natural dispatch (more passes than CUs);
+* the u-first early-out of the PERPIXEL triangle loop against the oracle on the same soups
+  (test_kernel_variants_on_random_soups covers it too; here with many passes per pixel);
+* the reference-side binding (integration/hip/Scene.h) EXECUTED on the GPU through a C++ host;
+* ptw_render_ex(num_devices > 1): a failing shard is an error, not a hang.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)))
+
+
+def _soup(pkg, ntri, nsph, seed, w=4, h=3):
+    """Random triangle / sphere soup inside an enclosing shell (long paths), all five material kinds."""
+    rng = np.random.default_rng(seed)
+    scene = pkg.Scene()
+    mats = [pkg.material("diffuse", rng.uniform(0.2, 0.9, 3)),
+            pkg.material("light", rng.uniform(0.5, 3.0, 3)),
+            pkg.material("glossy", rng.uniform(0.2, 0.9, 3), 1.3, 20.0),
+            pkg.material("reflective", rng.uniform(0.2, 0.9, 3), 0.5, 4.0),
+            pkg.material("specular", rng.uniform(0.2, 0.9, 3), 1.0)]
+    for i in range(ntri):
+        c = rng.uniform(-3, 3, 3)
+        v = c + rng.uniform(-0.6, 0.6, (3, 3))
+        scene.add_triangle(v[0], v[1], v[2], mats[i % len(mats)])
+    for i in range(nsph):
+        scene.add_sphere(rng.uniform(-3, 3, 3), rng.uniform(0.05, 0.4), mats[(i + 2) % len(mats)])
+    scene.add_sphere((0, 0, 0), 12.0, mats[0])
+    scene.set_environment_colour((0.1, 0.2, 0.3))
+    cam = pkg.set_focus(pkg.look_at((0, 0.5, 7), (0, 0, 0), (0, 1, 0), w, h, 45.0), (0, 0, 0), 0.02)
+    return scene, cam
+
+
+def _render_with_stats(pkg, scene, cam, params):
+    import torch
+    ctx = pkg.Context(0)
+    ctx.set_scene(scene)
+    ctx.enable_stats(True)
+    h, w, spp = params.height, params.width, params.samples_per_pixel
+    rgb = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+    cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    words = torch.zeros((spp, h, w), dtype=torch.int32, device="cuda")
+    ctx.render(cam, params, rgb.data_ptr(), cnt.data_ptr(), words.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    st = ctx.stats(reset=True)
+    return (rgb.cpu().numpy(), cnt.cpu().numpy().astype(np.uint32), words.cpu().numpy().astype(np.uint32),
+            st.trace_kernel.decode(), st.trace_launches)
+
+
+# (triangles, shading tables, the instantiation that must run) - ptw_kernels.hip dispatchSequential
+TWO_MASTER_CASES = [
+    (200, "lds", "traceSequential<1,6,lds,stack,2 masters>"),
+    (200, "global", "traceSequential<1,6,global,stack,2 masters>"),
+    (500, "lds", "traceSequential<2,6,lds,stack,2 masters>"),
+    (500, "global", "traceSequential<2,6,global,stack,2 masters>"),
+    (1000, "lds", "traceSequential<3,6,lds,stack,2 masters>"),
+    (1000, "global", "traceSequential<3,6,global,stack,2 masters>"),
+    (1200, "lds", "traceSequential<4,6,lds,stack,2 masters>"),
+    (1400, "global", "traceSequential<4,6,global,stack,2 masters>"),   # tables exceed the LDS budget on their own
+    (2000, "global", "traceSequential<6,6,global,stack,2 masters>"),
+    (3000, "global", "traceSequential<9,6,global,stack,2 masters>"),
+    (4000, "global", "traceSequential<12,6,global,stack,2 masters>"),
+]
+
+
+@pytest.mark.parametrize("ntri,tables,kernel", TWO_MASTER_CASES)
+@pytest.mark.parametrize("spp,budget_kb", [(3, None), (4, 1)])
+def test_two_master_kernels_match_oracle(pkg, ob, monkeypatch, ntri, tables, kernel, spp, budget_kb):
+    """Every <SLOTS, 6, lds|global, 2 masters> instantiation against the oracle: odd pass count (the
+    last workgroup's second master has no pass) in one band; even pass count with a staging budget
+    so small that every pass parks and resumes its generator after every few pixels."""
+    monkeypatch.setenv("PTW_SEQ_MM", "1")
+    if tables == "global" and ntri < 1400:
+        monkeypatch.setenv("PTW_SEQ_LDS_TABLES", "0")
+    if budget_kb:
+        monkeypatch.setenv("PTW_STAGE_BUDGET_KB", str(budget_kb))
+    w, h = (12, 10) if budget_kb else (4, 3)   # (a band is at least 64 pixels)
+    scene, cam = _soup(pkg, ntri, 2, seed=31 * ntri + spp, w=w, h=h)
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=5)
+    ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(scene.view(), cam, params, threads=4)
+    rgb, cnt, words, variant, launches = _render_with_stats(pkg, scene, cam, params)
+    assert variant == kernel, variant
+    if budget_kb:
+        assert launches > 1, "the staging budget did not cut the frame into bands"
+    assert np.array_equal(cnt, ref_cnt)
+    assert np.array_equal(words, ref_words), "a path decision diverged from the oracle"
+    assert rel_err(rgb, ref_rgb) < TOL
+
+
+@pytest.mark.parametrize("ntri,nsph", [(300, 0), (900, 70)])
+def test_two_master_natural_dispatch_more_passes_than_cus(pkg, ob, ntri, nsph):
+    """No switch: more passes than the device has CUs selects the two-master kernel by itself - the
+    situation of BASELINE cfg3 / cfg4.  An odd count, so that the last workgroup runs one master."""
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    spp = cus + 3
+    scene, cam = _soup(pkg, ntri, nsph, seed=ntri)
+    params = pkg.default_params(width=4, height=3, samples_per_pixel=spp, seed=9)
+    ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(scene.view(), cam, params, threads=8)
+    rgb, cnt, words, variant, _ = _render_with_stats(pkg, scene, cam, params)
+    assert variant.endswith(",2 masters>"), variant
+    assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words)
+    assert rel_err(rgb, ref_rgb) < TOL
+
+
+@pytest.mark.parametrize("name,edge,spp", [("suzanne", 16, 6), ("ce", 6, 5)])
+def test_two_master_kernels_on_the_baseline_scenes(pkg, ob, monkeypatch, name, edge, spp):
+    """suzanne (<3,6,lds,2 masters>) and ce (<9,6,global,2 masters>) - the scenes of cfg3 / cfg4 -
+    directly against the oracle under the two-master kernel."""
+    monkeypatch.setenv("PTW_SEQ_MM", "1")
+    scene = pkg.Scene()
+    cam = scene.build_named(name, edge, edge)
+    params = pkg.default_params(width=edge, height=edge, samples_per_pixel=spp, seed=1)
+    ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(scene.view(), cam, params, threads=6)
+    rgb, cnt, words, variant, _ = _render_with_stats(pkg, scene, cam, params)
+    assert variant.endswith(",2 masters>"), variant
+    assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words)
+    assert rel_err(rgb, ref_rgb) < TOL
+
+
+@pytest.mark.parametrize("ntri,nsph", [(130, 1), (700, 3), (3442, 3)])
+@pytest.mark.parametrize("kernel", ["persistent", "legacy"])
+def test_perpixel_kernels_many_passes_match_oracle(pkg, ob, monkeypatch, ntri, nsph, kernel):
+    """PERPIXEL policy, both kernels, 40 passes of a small frame (incoherent rays in every wave - the
+    case the wave-uniform u-first early-out of the triangle loop is for): exact word counts and sums."""
+    monkeypatch.setenv("PTW_PIX_KERNEL", kernel)
+    scene, cam = _soup(pkg, ntri, nsph, seed=7 * ntri, w=6, h=4)
+    params = pkg.default_params(width=6, height=4, samples_per_pixel=40, seed=2, rng_policy=1)
+    ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(scene.view(), cam, params, threads=8)
+    rgb, cnt, words, variant, _ = _render_with_stats(pkg, scene, cam, params)
+    assert variant == ("tracePerPixelPersistent" if kernel == "persistent" else "tracePerPixel")
+    assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words)
+    assert rel_err(rgb, ref_rgb) < TOL
+
+
+# ---- multi-GPU: the collective bodies and the sharded render on ONE GPU -------------------------
+def _expected_gather(frames, root):
+    """ptw_comm_gather_rows' contract (= sharding.gather_rows): rank r's rows r, r + world, ... land in
+    the same rows of the root's buffer; the root's other content stays."""
+    world = len(frames)
+    out = frames[root].copy()
+    for r in range(world):
+        if r != root:
+            out[r::world] = frames[r][r::world]
+    return out
+
+
+@pytest.mark.parametrize("world,w,h,root", [(2, 9, 7, 0), (3, 5, 11, 0), (4, 6, 3, 2), (3, 4, 2, 1)])
+def test_loopback_collectives(pkg, world, w, h, root):
+    """The pack / slot arithmetic / unpack code of ptw_comm_gather_rows and the reduce, executed with
+    `world` ranks on this box's GPU through the loopback transport (one host thread per rank, each on
+    its own stream), against the definition.  Heights that do not divide by the world size, fewer
+    rows than ranks (a rank that owns nothing), a root other than 0."""
+    import threading
+    import torch
+    rng = np.random.default_rng(world * 100 + h)
+    rgb_host = [rng.uniform(0, 5, (h, w, 3)) for _ in range(world)]
+    cnt_host = [rng.integers(0, 1000, (h, w)).astype(np.uint32) for _ in range(world)]
+    comms = pkg.Comm.create_loopback(world, 0)
+    for mode in ("gather", "reduce"):
+        rgb = [torch.tensor(a, device="cuda") for a in rgb_host]
+        cnt = [torch.tensor(a.astype(np.int32), device="cuda") for a in cnt_host]
+        streams = [torch.cuda.Stream() for _ in range(world)]
+        torch.cuda.synchronize()
+        errors = []
+
+        def run(r):
+            try:
+                if mode == "gather":
+                    comms[r].gather_rows(rgb[r].data_ptr(), cnt[r].data_ptr(), w, h, root, streams[r].cuda_stream)
+                else:
+                    comms[r].reduce_framebuffer(rgb[r].data_ptr(), cnt[r].data_ptr(), w * h, root, streams[r].cuda_stream)
+            except Exception as e:  # noqa: BLE001
+                errors.append((r, e))
+
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=60)
+            assert not t.is_alive(), "a rank is stuck in the collective"
+        assert not errors, errors
+        torch.cuda.synchronize()
+        got_rgb, got_cnt = rgb[root].cpu().numpy(), cnt[root].cpu().numpy().astype(np.uint32)
+        if mode == "gather":
+            assert np.array_equal(got_rgb, _expected_gather(rgb_host, root))
+            assert np.array_equal(got_cnt, _expected_gather(cnt_host, root))
+        else:
+            want = rgb_host[root].copy()
+            for r in range(world):
+                if r != root:
+                    want = want + rgb_host[r]       # the root adds the peers in rank order
+            assert np.array_equal(got_rgb, want)
+            assert np.array_equal(got_cnt, sum(c.astype(np.uint64) for c in cnt_host).astype(np.uint32))
+        for r in range(world):                       # the other ranks' buffers are left as they were
+            if r != root:
+                assert np.array_equal(rgb[r].cpu().numpy(), rgb_host[r])
+    for c in comms:
+        c.close()
+
+
+@pytest.mark.parametrize("policy,n", [(0, 2), (0, 3), (1, 2), (1, 3)])
+def test_render_ex_sharded_code_path_on_one_gpu(pkg, policy, n):
+    """ptw_render_ex(num_devices = n, share_device = 2): the N-GPU render itself - a host thread,
+    context and stream per shard, pass ranges + reduce / interleaved rows + gather - with the
+    collective carried by the loopback transport; against the single-device render, starting from a
+    non-empty framebuffer (ArrayOutput +=)."""
+    w, h, spp = 20, 13, 7
+    scene = pkg.Scene()
+    cam = scene.build_named("cornell", w, h)
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=3, rng_policy=policy)
+    rng = np.random.default_rng(5)
+    rgb0, cnt0 = rng.uniform(0, 1, (h, w, 3)), rng.integers(0, 9, (h, w)).astype(np.uint32)
+    one_rgb, one_cnt = pkg.render(scene, cam, params, rgb_sum=rgb0.copy(), counts=cnt0.copy())
+    seen = []
+    many_rgb, many_cnt = pkg.render(scene, cam, params, rgb_sum=rgb0.copy(), counts=cnt0.copy(), num_devices=n,
+                                    share_device=2, progress=lambda done, total: seen.append((done, total)) and False)
+    assert np.array_equal(many_cnt, one_cnt) and np.all(many_cnt == cnt0 + spp)
+    if policy == 1:
+        assert np.array_equal(many_rgb, one_rgb)     # a gather moves bytes
+    else:
+        assert rel_err(many_rgb, one_rgb) < TOL     # pass ranges are added in another order
+    assert seen and seen[-1][0] == seen[-1][1]
+
+
+FAIL_SCRIPT = r"""
+import sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import torch  # noqa: F401  (one HIP runtime per process)
+import __graft_entry__ as entry
+pkg = entry.load_package()
+scene = pkg.Scene()
+cam = scene.build_named("cornell", 16, 12)
+params = pkg.default_params(width=16, height=12, samples_per_pixel=4, seed=1, rng_policy={policy})
+try:
+    pkg.render(scene, cam, params, num_devices={n}, share_device=2, progress={progress})
+except pkg.PtwError as e:
+    print("PTW_ERROR", e.status, e)
+    sys.exit(0)
+print("NO_ERROR")
+sys.exit(3)
+"""
+
+
+@pytest.mark.parametrize("env,policy,n,expect", [
+    ({"PTW_TEST_FAIL_SHARD": "1"}, 0, 2, "PTW_TEST_FAIL_SHARD"),        # a peer never sets up
+    ({"PTW_TEST_FAIL_SHARD": "0"}, 1, 3, "PTW_TEST_FAIL_SHARD"),        # ... the root itself
+    ({"PTW_TEST_FAIL_COLLECTIVE": "1"}, 0, 3, "PTW_TEST_FAIL_COLLECTIVE"),  # a sender fails: the root waits for it
+    ({"PTW_TEST_FAIL_COLLECTIVE": "0"}, 1, 2, "PTW_TEST_FAIL_COLLECTIVE"),  # the root fails: the senders wait for it
+    ({}, 0, 2, "cancelled"),                                                # the progress callback cancels
+])
+def test_failing_shard_is_an_error_not_a_hang(pkg, tmp_path, env, policy, n, expect):
+    """ADVICE r2 / VERDICT r2 What's weak 2: a shard that fails before or inside the collective used
+    to leave its peers waiting forever.  Now every such render ends with the failing shard's error.
+    Run in a child process under a timeout, so that a regression shows as a failure, not a hung suite."""
+    from conftest import ROOT
+    progress = "(lambda done, total: True)" if expect == "cancelled" else "None"
+    script = tmp_path / "fail.py"
+    script.write_text(FAIL_SCRIPT.format(root=str(ROOT), policy=policy, n=n, progress=progress))
+    proc = subprocess.run(["python", str(script)], env=dict(os.environ, **env), capture_output=True, text=True,
+                          timeout=180)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    assert "PTW_ERROR" in proc.stdout and expect in proc.stdout, proc.stdout
+
+
+RCCL_RANK_SCRIPT = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+rank, world, uid_file, w, h = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], 9, 7
+import numpy as np
+import torch
+import __graft_entry__ as entry
+pkg = entry.load_package()
+if rank == 0:
+    uid = pkg.Comm.unique_id()
+    with open(uid_file + ".tmp", "wb") as f:
+        f.write(uid)
+    os.replace(uid_file + ".tmp", uid_file)
+else:
+    t0 = time.time()
+    while not os.path.exists(uid_file):
+        if time.time() - t0 > 60:
+            print("NO_UID"); sys.exit(4)
+        time.sleep(0.05)
+    uid = open(uid_file, "rb").read()
+try:
+    comm = pkg.Comm.create(uid, world, rank, 0)
+except pkg.PtwError as e:
+    print("RCCL_REFUSED", e)
+    sys.exit(5)
+rng = [np.random.default_rng(10 + r) for r in range(world)]
+rgb_all = [g.uniform(0, 5, (h, w, 3)) for g in rng]
+cnt_all = [g.integers(0, 1000, (h, w)).astype(np.int32) for g in rng]
+stream = torch.cuda.current_stream().cuda_stream
+for mode in ("gather", "reduce"):
+    rgb = torch.tensor(rgb_all[rank], device="cuda")
+    cnt = torch.tensor(cnt_all[rank], device="cuda")
+    if mode == "gather":
+        comm.gather_rows(rgb.data_ptr(), cnt.data_ptr(), w, h, 0, stream)
+    else:
+        comm.reduce_framebuffer(rgb.data_ptr(), cnt.data_ptr(), w * h, 0, stream)
+    torch.cuda.synchronize()
+    if rank == 0:
+        if mode == "gather":
+            want_rgb, want_cnt = rgb_all[0].copy(), cnt_all[0].copy()
+            for r in range(1, world):
+                want_rgb[r::world] = rgb_all[r][r::world]
+                want_cnt[r::world] = cnt_all[r][r::world]
+            ok = np.array_equal(rgb.cpu().numpy(), want_rgb) and np.array_equal(cnt.cpu().numpy(), want_cnt)
+        else:
+            ok = np.allclose(rgb.cpu().numpy(), sum(rgb_all), rtol=1e-15, atol=0) and \
+                np.array_equal(cnt.cpu().numpy(), sum(cnt_all))
+        print("RCCL_" + mode.upper(), "OK" if ok else "MISMATCH")
+comm.close()
+print("RANK_DONE", rank)
+"""
+
+
+def test_rccl_bodies_with_two_ranks_on_one_gpu(pkg, tmp_path):
+    """The RCCL transport itself (ncclReduce, grouped ncclSend / ncclRecv, pack / unpack) with TWO
+    ranks.  RCCL refuses two ranks of one host on one GPU; NCCL_HOSTID makes the two processes look
+    like two hosts, which moves the transfer onto RCCL's socket transport (loopback interface) - the
+    same calls, the same kernels, a slower wire.  Skipped, with the reason, where RCCL refuses that
+    too; the packing arithmetic is covered by test_loopback_collectives either way."""
+    from conftest import ROOT
+    script = tmp_path / "rank.py"
+    script.write_text(RCCL_RANK_SCRIPT.format(root=str(ROOT)))
+    uid_file = str(tmp_path / "uid.bin")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, NCCL_HOSTID=f"ptw-test-host-{r}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1",
+                   NCCL_P2P_DISABLE="1", NCCL_SHM_DISABLE="1", NCCL_DEBUG="WARN", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(["python", str(script), str(r), "2", uid_file], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=150)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.skip("RCCL did not complete a two-rank collective on one GPU within 150 s (socket transport)")
+        outs.append(out)
+    text = "\n".join(outs)
+    if "RCCL_REFUSED" in text or any(p.returncode not in (0,) for p in procs):
+        pytest.skip("RCCL refused two ranks on one GPU: " + text[-600:])
+    assert "RCCL_GATHER OK" in text and "RCCL_REDUCE OK" in text, text
+
+
+@pytest.mark.parametrize("scene,w,h,spp", [("cornell", 40, 30, 5), ("suzanne", 24, 16, 3)])
+def test_reference_side_binding_runs_on_the_gpu(pkg, scene, w, h, spp):
+    """integration/hip/Scene.h - the file a pt-three-ways maintainer would add as src/hip/Scene.h -
+    executed: SceneBuilder calls, render(camera, renderParams, updateFunc) with the running
+    ArrayOutput handed to updateFunc (src/dod/Scene.cpp:245), result compared with ptw_render inside
+    the host program (pt-three-ways_amd/host/integration_check.cpp)."""
+    from conftest import ROOT
+    exe = pkg.LIB_PATH.parent / "integration_check"
+    assert exe.exists(), "make -C pt-three-ways_amd integration_check"
+    proc = subprocess.run([str(exe), scene, str(w), str(h), str(spp), str(ROOT / "scenes")], capture_output=True,
+                          text=True, timeout=300)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    assert "INTEGRATION_OK" in proc.stdout and f"samples={w * h * spp}" in proc.stdout
+    assert int(proc.stdout.split("updates=")[1].split()[0]) >= 2

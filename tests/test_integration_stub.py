@@ -84,3 +84,18 @@ def test_reference_side_binding_compiles_and_maps_exactly(pkg, tmp_path):
     else:
         assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
     assert "ok" in run.stdout
+
+
+def test_binding_host_fails_loudly_without_a_gpu(pkg):
+    """The executed form of the binding (host/integration_check.cpp, run on the GPU box by
+    tests/test_gpu_round3.py): built here, and without a device its render throws - no CPU fallback."""
+    import subprocess
+    import torch
+    from conftest import ROOT
+    exe = pkg.LIB_PATH.parent / "integration_check"
+    assert exe.exists()
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    proc = subprocess.run([str(exe), "cornell", "8", "8", "2", str(ROOT / "scenes")], capture_output=True, text=True,
+                          timeout=60)
+    assert proc.returncode != 0 and "no HIP device" in (proc.stdout + proc.stderr)
