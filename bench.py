@@ -630,6 +630,14 @@ def main():
         rgb2 = torch.zeros_like(final[0])
         cnt2 = torch.zeros_like(final[1])
         stream = torch.cuda.current_stream().cuda_stream
+        # untimed warm-up (the analogue of the W warm-up steps): the library picks this policy's kernel
+        # with a timed trial at the first large render of a scene + frame shape
+        warm = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=args.seed, rng_policy=pkg.RNG_PERPIXEL,
+                                  device=local_rank, row_begin=0,
+                                  row_end=max(1, min(h, ((17 << 20) * world) // (w * spp) + world)),
+                                  **(sharding.interleaved_rows(rank, world) if world > 1 else {}))
+        ctx.render(cam, warm, scratch[0].data_ptr(), scratch[1].data_ptr(), 0, stream)
+        torch.cuda.synchronize()
         ctx.enable_stats(True)
         ctx.stats(reset=True)
         if use_dist:

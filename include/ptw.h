@@ -235,7 +235,9 @@ int ptw_context_set_scene(ptw_context *ctx, const ptw_scene_view *scene);
 /* Enqueue the render on `hip_stream` (a hipStream_t, NULL = default stream).  d_rgb_sum and
  * d_counts are DEVICE pointers to width*height*3 doubles / width*height uint32 and are
  * accumulated into.  Asynchronous: nothing here waits for the device; the caller synchronises
- * the stream.  A context owns one set of scratch buffers (generator states, staging): renders
+ * the stream.  (One exception: the first PTW_RNG_PERPIXEL render of 16 M samples or more after
+ * ptw_context_set_scene times a trial of the policy's two kernels - about two million samples each -
+ * to pick the faster one for this scene and frame shape, and waits for that trial.)  A context owns one set of scratch buffers (generator states, staging): renders
  * of one context must be enqueued on the SAME stream (they then run one after another in stream
  * order); to change streams, or before ptw_context_set_scene, synchronise the stream of the
  * previous render.  Renders on different contexts are independent.  If d_words is not NULL it receives, per pass and pixel

@@ -94,6 +94,11 @@ struct ptw_context {
   // context, see include/ptw.h).
   std::vector<uint32_t> hostSeedStates, hostPos;
   hipEvent_t uploadsDone = nullptr; // recorded after a render's uploads: the host vectors are free again
+  // PERPIXEL: which of the two kernels this scene + frame shape runs faster on (timed once, see
+  // choosePixKernel); 0 = not decided yet
+  uint64_t pixChoiceKey = 0;
+  int pixChoice = 0;
+  uint64_t sceneGeneration = 0;
   char traceKernel[64] = ""; // variant name of the last trace launch (a copy: the launcher's
                              // string lives in thread-local storage of the launching thread)
 
@@ -229,6 +234,74 @@ TraceParams makeTraceParams(const ptw_context &ctx, const ptw_camera &cam,
   return t;
 }
 
+// PERPIXEL policy: lock-step or persistent kernel (ptw_kernels.hip, launchTracePerPixel)?  Which
+// one is faster depends on how uniformly long the scene's paths are, which no host-side number
+// says: so the first large render of a scene + frame shape on a context times a trial of both -
+// about two million samples each, image rows spread over the whole frame, all passes' worth of
+// lanes - and the context remembers the winner.  The trial's outputs land in the staging buffer
+// (overwritten by the render) and nowhere else.  Renders below 16 M samples, A/B overrides
+// (PTW_PIX_KERNEL) and the accelerated mode do not calibrate.  This is the one place where
+// ptw_context_render waits for the device (a few tens of milliseconds, once).
+int choosePixKernel(ptw_context &ctx, const TraceParams &t, const TraceBuffers &b, const RowSet &rows,
+                    uint32_t bandPix, hipStream_t stream) {
+  if (std::getenv("PTW_PIX_KERNEL") || t.accel != PTW_ACCEL_NONE) return kPixKernelAuto;
+  const uint64_t total = static_cast<uint64_t>(rows.count) * t.width * t.npass;
+  if (total < (16ull << 20)) return kPixKernelAuto;
+  // FNV-1a over what the decision depends on
+  uint64_t key = 1469598103934665603ull;
+  auto mix = [&](const void *data, size_t n) {
+    const unsigned char *c = static_cast<const unsigned char *>(data);
+    for (size_t i = 0; i < n; ++i) key = (key ^ c[i]) * 1099511628211ull;
+  };
+  mix(&ctx.sceneGeneration, sizeof ctx.sceneGeneration);
+  mix(&t.cam, sizeof t.cam);
+  const int32_t shape[7] = {t.width, t.height, t.maxDepth, t.fbU, t.fbV, t.preview, rows.stride};
+  mix(shape, sizeof shape);
+  if (ctx.pixChoice != 0 && ctx.pixChoiceKey == key) return ctx.pixChoice;
+
+  TraceParams tt = t;
+  tt.npass = std::min<uint32_t>(t.npass, 32);
+  uint32_t trialRows = static_cast<uint32_t>(std::max<uint64_t>(1, (2ull << 20) / (static_cast<uint64_t>(t.width) * tt.npass)));
+  trialRows = std::min<uint32_t>(trialRows, static_cast<uint32_t>(rows.count));
+  trialRows = std::min<uint32_t>(trialRows, std::max<uint32_t>(1, bandPix / static_cast<uint32_t>(t.width)));
+  tt.rowFirst = rows.first;
+  tt.rowStride = rows.stride * std::max<int>(1, rows.count / static_cast<int>(trialRows)); // spread over the frame
+  tt.pixBegin = 0;
+  tt.pixCount = trialRows * static_cast<uint32_t>(t.width);
+  TraceBuffers bb = b;
+  bb.rays = nullptr;  // the trial is not part of the render's statistics
+  bb.words = nullptr;
+  hipEvent_t ev[3];
+  for (auto &e : ev) check(hipEventCreate(&e), "hipEventCreate");
+  float ms[2] = {0, 0};
+  try {
+    for (int warm = 1; warm >= 0; --warm) { // first pass: code objects loaded, tiny; second: timed
+      TraceParams run = tt;
+      if (warm) run.pixCount = std::min<uint32_t>(run.pixCount, 256), run.npass = 1;
+      check(hipEventRecord(ev[0], stream), "hipEventRecord");
+      run.pixKernel = kPixKernelLockstep;
+      check(launchTracePerPixel(run, bb, stream), "trial launch");
+      check(hipEventRecord(ev[1], stream), "hipEventRecord");
+      run.pixKernel = kPixKernelPersistent;
+      check(launchTracePerPixel(run, bb, stream), "trial launch");
+      check(hipEventRecord(ev[2], stream), "hipEventRecord");
+    }
+    check(hipEventSynchronize(ev[2]), "hipEventSynchronize");
+    check(hipEventElapsedTime(&ms[0], ev[0], ev[1]), "hipEventElapsedTime");
+    check(hipEventElapsedTime(&ms[1], ev[1], ev[2]), "hipEventElapsedTime");
+  } catch (...) {
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    throw;
+  }
+  for (auto &e : ev) (void)hipEventDestroy(e);
+  ctx.pixChoiceKey = key;
+  ctx.pixChoice = ms[0] < ms[1] ? kPixKernelLockstep : kPixKernelPersistent;
+  if (std::getenv("PTW_PIX_TRACE"))
+    std::fprintf(stderr, "ptw: PERPIXEL trial (%u rows x %d x %u passes): lock-step %.3f ms, persistent %.3f ms -> %s\n",
+                 trialRows, t.width, tt.npass, ms[0], ms[1], ctx.pixChoice == kPixKernelLockstep ? "lock-step" : "persistent");
+  return ctx.pixChoice;
+}
+
 // Enqueues the whole render on `stream`.  `betweenBands`, when set, is called after each
 // band's launches have been enqueued with the band's local pixel range and the samples enqueued so
 // far; returning true cancels.  `minBands` > 1 cuts the frame into at least that many bands.
@@ -348,6 +421,8 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
     ctx.timed.push_back(ev);
   };
 
+  if (!sequential) t.pixKernel = choosePixKernel(ctx, t, b, rows, static_cast<uint32_t>(bandPix), stream);
+
   uint64_t done = 0;
   for (uint32_t begin = 0; begin < pixTotal;) {
     t.pixBegin = begin;
@@ -429,6 +504,8 @@ int ptw_context_set_scene(ptw_context *ctx, const ptw_scene_view *scene) {
   ctx->triMaterial = std::move(data.triMaterial);
   ctx->sphMaterial = std::move(data.sphMaterial);
   ctx->haveScene = true;
+  ctx->sceneGeneration++;
+  ctx->pixChoice = 0;
   return PTW_OK;
   PTW_GUARD_END
 }

@@ -33,7 +33,9 @@ struct TraceParams {
   int32_t rowFirst;      // image row of local row 0
   int32_t rowStride;     // image rows between consecutive local rows (>= 1)
   int32_t accel;         // ptw_accel: PERPIXEL only
+  int32_t pixKernel;     // PERPIXEL: 0 = launcher's default, 1 = lock-step (grid-stride), 2 = persistent
 };
+constexpr int kPixKernelAuto = 0, kPixKernelLockstep = 1, kPixKernelPersistent = 2;
 
 // Global (row-major, full-frame) index of local pixel l.
 __host__ __device__ inline uint32_t globalPixel(const TraceParams &p, uint32_t l) {

@@ -1887,8 +1887,8 @@ struct PixCtxT {
     TriRegs cur = loadTriScalar(triGeom, 0);
     for (uint32_t k = 0; k < ntri; ++k) {
       const TriRegs nxt = loadTriScalar(triGeom, k + 1 < ntri ? k + 1 : k);
-      testTriangle(o, d, mk(cur.v[0], cur.v[1], cur.v[2]), mk(cur.v[3], cur.v[4], cur.v[5]),
-                   mk(cur.v[6], cur.v[7], cur.v[8]), nsph + k, key.t, key.idx, key.det);
+      testTriangleUFirst(o, d, mk(cur.v[0], cur.v[1], cur.v[2]), mk(cur.v[3], cur.v[4], cur.v[5]),
+                         mk(cur.v[6], cur.v[7], cur.v[8]), nsph + k, key.t, key.idx, key.det);
       cur = nxt;
     }
     return key;
@@ -1907,9 +1907,11 @@ constexpr int kPixBlock = 256;
 // loop has no latency left to hide, and 4 waves (128 VGPRs, 160 B/lane of scratch) measured the same.
 template <bool BVH>
 __device__ __forceinline__ void perPixelSample(const TraceParams &p, const TraceBuffers &b, uint32_t *ldsWords) {
-  const uint64_t gid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
-  if (gid >= total) return;
+  // grid-stride: a lane traces sample gid, gid + grid, ... one after another (launchTracePerPixel
+  // sizes the grid for kPixSamplesPerLane samples per lane; 1 = one sample per lane per launch)
+  for (uint64_t gid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; gid < total;
+       gid += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
   // consecutive lanes = consecutive pixels of one pass (coalesced stage writes)
   const uint32_t pass = static_cast<uint32_t>(gid / p.pixCount);
   const uint32_t i = static_cast<uint32_t>(gid % p.pixCount);
@@ -1946,6 +1948,7 @@ __device__ __forceinline__ void perPixelSample(const TraceParams &p, const Trace
   out[0] = L.x, out[1] = L.y, out[2] = L.z;
   if (b.words) b.words[static_cast<size_t>(pass) * p.npix + pix] = ctx.words;
   if (b.rays) atomicAdd(&b.rays[pass], ctx.rays);
+  }
 }
 
 __global__ __launch_bounds__(kPixBlock) __attribute__((amdgpu_waves_per_eu(PTW_PIX_WAVES, PTW_PIX_WAVES))) void tracePerPixel(
@@ -2105,14 +2108,20 @@ __global__ __launch_bounds__(kPix2Block) __attribute__((amdgpu_waves_per_eu(W, W
             const double invDet = rcp(det);
             const d3 tVec = o - v0;
             const double u = dot(tVec, pVec) * invDet;
-            const d3 qVec = cross(tVec, e1);
-            const double v = dot(d, qVec) * invDet;
-            if (!((u < 0.0) | (u > 1.0) | (v < 0.0) | (u + v > 1))) {
-              const double t = dot(e2, qVec) * invDet;
-              if (t > kEpsilon && t < key.t) {
-                key.t = t;
-                key.idx = nsph + k;
-                key.det = det;
+            // u first: the reference rejects on (u < 0 | u > 1 | v < 0 | u + v > 1) as one fused test
+            // (Scene.cpp:89); a triangle rejected on u is rejected whatever v is, so when no lane of
+            // the wave passes the u test the wave skips qVec, v and t (18 of the test's 50 issue
+            // slots) - same decisions, same values.
+            if (!PTW_U_FIRST || !((u < 0.0) | (u > 1.0))) {
+              const d3 qVec = cross(tVec, e1);
+              const double v = dot(d, qVec) * invDet;
+              if (PTW_U_FIRST ? !((v < 0.0) | (u + v > 1)) : !((u < 0.0) | (u > 1.0) | (v < 0.0) | (u + v > 1))) {
+                const double t = dot(e2, qVec) * invDet;
+                if (t > kEpsilon && t < key.t) {
+                  key.t = t;
+                  key.idx = nsph + k;
+                  key.det = det;
+                }
               }
             }
           }
@@ -2528,10 +2537,16 @@ hipError_t dispatchSequential(const TraceParams &p, const TraceBuffers &b, hipSt
 
 hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipStream_t stream,
                                const char **variant) {
-  // The persistent kernel (lanes that finish a path take the next sample) is the default for every
-  // scene: measured against the lock-step kernel it runs 1.25x (Cornell) to 2.9x (bbc-owl) on the
-  // small scenes as well (profiles/r02q_lockstep_vs_persistent_small_scenes.txt).  PTW_PIX_KERNEL
-  // (legacy|persistent) overrides for A/B runs; the accelerated mode has its own kernel.
+  // Two kernels, each the better one somewhere (one box, one run: profiles/r03a_perpixel_*):
+  //   lock-step (tracePerPixel, a lane traces a whole sample, 8 samples per lane through a
+  //     grid-stride loop): Cornell 1024x1024 @ 256 spp 224 Msamples/s against 146 - in a closed scene
+  //     nearly every path runs to the depth cap, the lanes of a wave stay together, and the
+  //     shading code runs once per level for all of them;
+  //   persistent (tracePerPixelPersistent, lanes that finish a path take the next sample): suzanne
+  //     44 against 19, bbc-owl 395 against 139 - open scenes, where most paths of a wave end early.
+  // p.pixKernel carries the caller's choice (capi_render.hip times a trial of both once per scene
+  // and frame shape); without one the persistent kernel runs.  PTW_PIX_KERNEL (legacy|persistent)
+  // overrides for A/B runs; the accelerated mode has its own kernel.
   const char *forced = std::getenv("PTW_PIX_KERNEL");
   if (p.accel == PTW_ACCEL_BVH) {
     if (variant) *variant = "tracePerPixelBvh";
@@ -2547,7 +2562,7 @@ hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipS
     hipLaunchKernelGGL(tracePerPixelBvh, dim3(blocks), dim3(kPixBlock), lds, stream, p, b);
     return hipGetLastError();
   }
-  const bool persistent = forced ? std::string(forced) != "legacy" : true;
+  const bool persistent = forced ? std::string(forced) != "legacy" : p.pixKernel != kPixKernelLockstep;
   if (variant) *variant = persistent ? "tracePerPixelPersistent" : "tracePerPixel";
   if (persistent) {
     const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
@@ -2585,7 +2600,13 @@ hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipS
     return hipGetLastError();
   }
   const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
-  const uint32_t blocks = static_cast<uint32_t>((total + kPixBlock - 1) / kPixBlock);
+  // PTW_PIX_SPL=n: n samples per lane through the kernel's grid-stride loop (default 8; 1 = a block
+  // per 256 samples)
+  const char *splEnv = std::getenv("PTW_PIX_SPL");
+  // (measured on Cornell 1024x1024 @ 256: 1 -> 194, 4 -> 223, 16 -> 224, 64 -> 219, 256 -> 201 Msamples/s:
+  // a block per 256 samples is a million block dispatches per frame)
+  const uint64_t spl = splEnv && std::atoi(splEnv) > 0 ? static_cast<uint64_t>(std::atoi(splEnv)) : 8;
+  const uint32_t blocks = static_cast<uint32_t>((total + kPixBlock * spl - 1) / (kPixBlock * spl));
   const int levels = p.maxDepth > 1 ? p.maxDepth - 1 : 1;
   const size_t lds = static_cast<size_t>(levels) * kPixBlock * sizeof(uint32_t);
   if (lds > 48 * 1024) {

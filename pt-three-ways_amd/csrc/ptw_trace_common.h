@@ -61,6 +61,38 @@ __device__ __forceinline__ void testTriangle(d3 o, d3 d, d3 v0, d3 e1, d3 e2, ui
   }
 }
 
+// The same test for kernels in which all lanes of a wave test the SAME triangle (PERPIXEL policy):
+// u is decided first.  The reference rejects on (u < 0 | u > 1 | v < 0 | u + v > 1) as one fused test
+// (Scene.cpp:89); a triangle rejected on u is rejected whatever v is, so when no lane passes the u
+// test the wave skips qVec, v and t - same decisions, same values.
+// -DPTW_U_FIRST=0: the fused test everywhere (A/B builds: make alt ALT_FLAGS=-DPTW_U_FIRST=0)
+#ifndef PTW_U_FIRST
+#define PTW_U_FIRST 1
+#endif
+__device__ __forceinline__ void testTriangleUFirst(d3 o, d3 d, d3 v0, d3 e1, d3 e2, uint32_t idx,
+                                                   double &bestT, uint32_t &bestIdx, double &bestDet) {
+#if !PTW_U_FIRST
+  testTriangle(o, d, v0, e1, e2, idx, bestT, bestIdx, bestDet);
+  return;
+#endif
+  const d3 pVec = cross(d, e2);
+  const double det = dot(e1, pVec);
+  if (__builtin_fabs(det) < kEpsilon) return;
+  const double invDet = rcp(det);
+  const d3 tVec = o - v0;
+  const double u = dot(tVec, pVec) * invDet;
+  if ((u < 0.0) | (u > 1.0)) return;
+  const d3 qVec = cross(tVec, e1);
+  const double v = dot(d, qVec) * invDet;
+  if ((v < 0.0) | (u + v > 1)) return;
+  const double t = dot(e2, qVec) * invDet;
+  if (t > kEpsilon && t < bestT) {
+    bestT = t;
+    bestIdx = idx;
+    bestDet = det;
+  }
+}
+
 // One sphere test, Scene.cpp:17-35.
 __device__ __forceinline__ void testSphere(d3 o, d3 d, d3 centre, double radiusSquared,
                                            uint32_t idx, double &bestT, uint32_t &bestIdx) {

@@ -377,3 +377,34 @@ def test_reference_side_binding_runs_on_the_gpu(pkg, scene, w, h, spp):
     assert proc.returncode == 0, proc.stdout + proc.stderr
     assert "INTEGRATION_OK" in proc.stdout and f"samples={w * h * spp}" in proc.stdout
     assert int(proc.stdout.split("updates=")[1].split()[0]) >= 2
+
+
+@pytest.mark.parametrize("name,want", [("cornell", "tracePerPixel"), ("bbc-owl", "tracePerPixelPersistent")])
+def test_perpixel_kernel_is_chosen_by_a_timed_trial(pkg, name, want):
+    """PERPIXEL policy: a render of 16 M samples or more times a trial of the lock-step and the
+    persistent kernel once per scene + frame shape and runs the faster one - the lock-step kernel in
+    the closed Cornell box (measured 224 against 146 Msamples/s at the BASELINE shape), the persistent
+    one in open scenes (bbc-owl 395 against 139).  Small renders do not calibrate.  Whichever runs,
+    the bytes are the same (tests/test_gpu_cli.py compares the kernels' .raw files)."""
+    import torch
+    w = h = 512
+    scene = pkg.Scene()
+    cam = scene.build_named(name, w, h)
+    ctx = pkg.Context(0)
+    ctx.set_scene(scene)
+    ctx.enable_stats(True)
+    rgb = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+    cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    small = pkg.default_params(width=w, height=h, samples_per_pixel=2, seed=1, rng_policy=1)
+    ctx.render(cam, small, rgb.data_ptr(), cnt.data_ptr(), 0, stream)
+    torch.cuda.synchronize()
+    assert ctx.stats(reset=True).trace_kernel.decode() == "tracePerPixelPersistent"
+    big = pkg.default_params(width=w, height=h, samples_per_pixel=64, seed=1, rng_policy=1)
+    for _ in range(2):      # the second render reuses the decision
+        ctx.render(cam, big, rgb.data_ptr(), cnt.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+        st = ctx.stats(reset=True)
+        assert st.trace_kernel.decode() == want
+        assert st.samples == w * h * 64 and st.rays > 0      # the trial is not in the statistics
+    assert int(cnt.min().item()) == 2 + 128 and int(cnt.max().item()) == 2 + 128
