@@ -86,7 +86,8 @@ struct ptw_context {
   DeviceArray<double> stage;
   DeviceArray<unsigned long long> sampleQueue; // work counter of the persistent kernel
   DeviceArray<unsigned long long> countHist; // traceSequentialWide: committed sub-samples by levels reached
-  DeviceArray<unsigned char> wideCands;      // traceSequentialWide: the candidate set of the current band
+  DeviceArray<unsigned char> wideCands;      // the many-candidate kernels: the candidate set of the current band
+  DeviceArray<unsigned char> gangRecords;    // traceSequentialGang: result exchange between the CUs of a pass
   DeviceArray<unsigned long long> rays; // per-pass intersect() counters, accumulated
   uint64_t rayCarry = 0;                // counts folded in when `rays` had to grow
   // Host sources of the asynchronous uploads of a render; they live in the context because
@@ -338,16 +339,17 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   if (minBands > 1) bandPix = std::min<uint64_t>(bandPix, (pixTotal + minBands - 1) / minBands);
   bandPix = std::max<uint64_t>(bandPix, 64);
   bandPix = std::min<uint64_t>(bandPix, pixTotal);
-  // (experiments build) The wide sequential kernel picks its speculation candidates per band from the statistics of
+  // The many-candidate sequential kernels (traceSequentialGang; the experiments build's wide kernels)
+  // pick their speculation candidates per band from the statistics of
   // the band before: give it a short first band to measure on and at least eight bands, so that
   // the set follows the image from top to bottom.
+  TraceParams shape = t; // (what the dispatcher looks at: scene size, depth, pass count)
+  bool adaptive = sequential && pixTotal >= 16384 && seqGangGroups(shape) > 0;
 #if PTW_EXPERIMENTS
   const char *wideEnv = std::getenv("PTW_SEQ_WIDE");
   const char *spec8Env = std::getenv("PTW_SEQ_SPEC8");
-  const bool adaptive = sequential && pixTotal >= 16384 && ctx.ntri <= 64 &&
-                        ((wideEnv && wideEnv[0] == '1' && wideKernelApplies(t)) || (spec8Env && spec8Env[0] == '1'));
-#else
-  const bool adaptive = false;
+  adaptive = adaptive || (sequential && pixTotal >= 16384 && ctx.ntri <= 64 &&
+                          ((wideEnv && wideEnv[0] == '1' && wideKernelApplies(t)) || (spec8Env && spec8Env[0] == '1')));
 #endif
   if (adaptive) bandPix = std::min<uint64_t>(bandPix, (pixTotal + 7) / 8);
   // equal bands (the last one is not a sliver)
@@ -393,18 +395,20 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   ctx.sampleQueue.reserve(1);
   b.sampleQueue = ctx.sampleQueue.ptr;
   b.specState = sequential ? ctx.specState.ptr : nullptr;
-#if PTW_EXPERIMENTS
   if (sequential && !ctx.countHist.ptr) {
     ctx.countHist.reserve(8);
     check(hipMemsetAsync(ctx.countHist.ptr, 0, 8 * sizeof(unsigned long long), stream), "memset");
   }
-  ctx.wideCands.reserve(wideCandidateBytes());
-#endif
+  if (sequential) {
+    ctx.wideCands.reserve(wideCandidateBytes());
+    ctx.gangRecords.reserve(gangRecordBytes(npass));
+  }
   b.bvhNodes = ctx.bvhNodes.ptr;
   b.bvhLeafGeom = ctx.bvhLeafGeom.ptr;
   b.bvhLeafIndex = ctx.bvhLeafIndex.ptr;
-  b.countHist = ctx.countHist.ptr; // (experiments only: null in the shipped library)
+  b.countHist = ctx.countHist.ptr;
   b.wideCands = ctx.wideCands.ptr;
+  b.gangRecords = ctx.gangRecords.ptr;
 
   auto timedLaunch = [&](bool trace, auto &&launch) {
     if (!ctx.statsEnabled) {

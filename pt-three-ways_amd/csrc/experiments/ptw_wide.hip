@@ -769,67 +769,6 @@ __global__ __launch_bounds__(kWideBlock) void traceSequentialWide(
   }
 }
 
-// The candidate set: prefix-closed greedy on the probability that the true chain reaches a node
-// with every node before it in the set (= the expected number of sub-samples a round commits),
-// for sub-sample draw counts distributed like the histogram the previous band of this render
-// measured (`hist[k]`: committed sub-samples that reached k + 1 levels, i.e. consumed 3 (k + 1)
-// draws; read and reset here) or, while there is too little of it, like a prior.  One lane; it
-// runs once per band, in stream order before the band's trace kernel.
-constexpr int kCandMaxM = 17, kCandMaxK = 5 * kCandMaxM + 1;
-__global__ __launch_bounds__(64) void wideBuildCandidates(unsigned long long *__restrict__ hist, int n, int nSub,
-                                                          int maxAhead, WideCandidates *__restrict__ out) {
-  __shared__ float reach[kCandMaxM][kCandMaxK]; // frontier: reach probability if the node were added
-  __shared__ unsigned char taken[kCandMaxM][kCandMaxK]; // 1 + candidate index
-  if (threadIdx.x != 0) return;
-  // sub-samples that consume 3, 6, 9, 12, 15 (and more) draws: a closed box mostly runs every path
-  // to the depth cap, an open scene mostly loses the first ray
-  float prob[6] = {0.f, 0.01f, 0.23f, 0.12f, 0.09f, 0.55f};
-  unsigned long long total = 0;
-  for (int k = 0; k < 5; ++k) total += hist[k];
-  if (total >= 4096) {
-    for (int k = 0; k < 5; ++k) prob[k + 1] = static_cast<float>(static_cast<double>(hist[k]) / static_cast<double>(total));
-  }
-  for (int k = 0; k < 5; ++k) hist[k] = 0;
-  for (int m = 0; m < kCandMaxM; ++m)
-    for (int k = 0; k < kCandMaxK; ++k) reach[m][k] = 0.f, taken[m][k] = 0;
-  auto expand = [&](int m, int k, float r) {
-    if (m + 1 >= nSub || m + 1 >= kCandMaxM) return;
-    for (int c = 1; c <= 5; ++c)
-      if (prob[c] > 0.f && 3 * (k + c) <= maxAhead) reach[m + 1][k + c] += r * prob[c];
-  };
-  int count = 0, maxD = 0;
-  out->node[count++] = 0;
-  taken[0][0] = 1;
-  expand(0, 0, 1.f);
-  while (count < n) {
-    int bm = -1, bk = 0;
-    float best = 0.f;
-    for (int m = 1; m < kCandMaxM; ++m)
-      for (int k = m; k <= 5 * m; ++k)
-        if (!taken[m][k] && reach[m][k] > best) best = reach[m][k], bm = m, bk = k;
-    if (bm < 0) break;
-    taken[bm][bk] = static_cast<unsigned char>(count + 1);
-    out->node[count++] = static_cast<uint16_t>((bm << 8) | (3 * bk));
-    maxD = 3 * bk > maxD ? 3 * bk : maxD;
-    expand(bm, bk, best);
-  }
-  for (int i = count; i < kWideMaxCand; ++i) out->node[i] = 0xffffu;
-  for (int i = 0; i < kWideMaxCand; ++i) {
-    uint32_t row = 0;
-    for (int c = 1; c <= 5; ++c) {
-      uint32_t next = 63;
-      if (i < count) {
-        const int m = out->node[i] >> 8, k = (out->node[i] & 0xff) / 3;
-        if (m + 1 < kCandMaxM && k + c < kCandMaxK && taken[m + 1][k + c]) next = taken[m + 1][k + c] - 1u;
-      }
-      row |= next << (6 * (c - 1));
-    }
-    out->succ[i] = row;
-  }
-  out->count = count;
-  out->maxD = maxD;
-}
-
 template <int G, int SLOTS>
 hipError_t launchWide(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
   auto kernel = traceSequentialWide<G, SLOTS>;
@@ -851,16 +790,6 @@ bool wideKernelApplies(const TraceParams &p) {
          wideLdsBytes(p.ntri, p.nmat, p.nsph) <= 150 * 1024;
 }
 
-size_t wideCandidateBytes() { return sizeof(WideCandidates); }
-
-hipError_t launchBuildCandidates(const TraceParams &p, const TraceBuffers &b, int n, hipStream_t stream) {
-  // A round reads up to maxD + 3 maxDepth draws beyond the frontier and only the frontier's block
-  // and the next one exist: candidates stay within 312 - 3 maxDepth - 8 draws of the frontier.
-  const int maxAhead = std::min(255, kMtDoubles - 3 * (p.maxDepth > 0 ? p.maxDepth : 1) - 8);
-  hipLaunchKernelGGL(wideBuildCandidates, dim3(1), dim3(64), 0, stream, b.countHist, n, p.fbU * p.fbV, maxAhead,
-                     reinterpret_cast<WideCandidates *>(b.wideCands));
-  return hipGetLastError();
-}
 
 hipError_t launchTraceSequentialWide(const TraceParams &p, const TraceBuffers &b, hipStream_t stream,
                                      const char **variant) {

@@ -34,8 +34,32 @@ struct TraceParams {
   int32_t rowStride;     // image rows between consecutive local rows (>= 1)
   int32_t accel;         // ptw_accel: PERPIXEL only
   int32_t pixKernel;     // PERPIXEL: 0 = launcher's default, 1 = lock-step (grid-stride), 2 = persistent
+  // SEQUENTIAL worker-wave kernels: resident triangles in units of 64 per worker wave - seqUnitsA
+  // for the waves that share a SIMD with another worker, seqUnitsB for those beside a master wave
+  // (set by the launcher, see seqUnitSplit)
+  int32_t seqUnitsA, seqUnitsB;
 };
 constexpr int kPixKernelAuto = 0, kPixKernelLockstep = 1, kPixKernelPersistent = 2;
+
+// How the worker-wave kernels spread a scene's ceil(ntri / 64) units of 64 triangles over their
+// worker waves.  A CU's four SIMDs carry eight waves: the master wave(s) and nB workers sit two to a
+// SIMD with each other, the other nA workers two to a SIMD among themselves.  The fp64 pipe of a
+// SIMD issues one wave instruction per four cycles whoever it comes from, so two workers on one
+// SIMD search at half speed each, while a worker beside a master has the SIMD to itself whenever
+// that master waits for this very search.  Equal shares therefore leave the search waiting for the
+// doubly loaded SIMDs; `ratio` (percent) is the share of a master-side worker relative to the
+// others.  Shares are capped at `maxUnits` (what the register file holds); what does not fit is
+// streamed from memory by all workers.
+__host__ __device__ inline void seqUnitSplit(uint32_t ntri, int nA, int nB, int ratio, int maxUnits, int &uA, int &uB) {
+  const int U = static_cast<int>((ntri + 63u) / 64u);
+  const int den = nA * 100 + nB * ratio;
+  uB = nB > 0 ? (U * ratio + den / 2) / den : 0;
+  if (uB > maxUnits) uB = maxUnits;
+  if (nB > 0 && uB * nB > U) uB = U / nB;
+  uA = nA > 0 ? (U - nB * uB + nA - 1) / nA : 0;
+  if (uA > maxUnits) uA = maxUnits;
+  if (uA < 0) uA = 0;
+}
 
 // Global (row-major, full-frame) index of local pixel l.
 __host__ __device__ inline uint32_t globalPixel(const TraceParams &p, uint32_t l) {
@@ -59,7 +83,8 @@ struct TraceBuffers {
   unsigned long long *sampleQueue; // one word: next sample index (tracePerPixelPersistent)
   double *specState;         // [npass][kSpecStateDoubles] parked stream ring (traceSequentialSpec / Wide)
   unsigned long long *countHist; // [8]: committed sub-samples by levels reached (traceSequentialWide)
-  void *wideCands;               // wideCandidateBytes(): the candidate set of traceSequentialWide
+  void *wideCands;               // wideCandidateBytes(): the candidate set of the many-candidate kernels
+  void *gangRecords;             // gangRecordBytes(npass): result exchange of traceSequentialGang (zeroed per launch)
   // accelerated mode (host/bvh.h)
   const void *bvhNodes;
   const double *bvhLeafGeom;
@@ -76,6 +101,11 @@ hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hi
 // per-sub-sample draw counts the previous launch left in countHist.
 bool wideKernelApplies(const TraceParams &p);
 size_t wideCandidateBytes();
+// traceSequentialGang (several CUs per pass, for renders with fewer passes than CUs): the number of
+// workgroups per pass the dispatcher will use for this launch shape on the current device (0: the
+// kernel does not apply), and the size of its exchange buffer.
+int seqGangGroups(const TraceParams &p);
+size_t gangRecordBytes(uint32_t npass);
 // Builds the candidate set (n candidates) for the next launch from b.countHist into b.wideCands.
 hipError_t launchBuildCandidates(const TraceParams &p, const TraceBuffers &b, int n, hipStream_t stream);
 hipError_t launchTraceSequentialWide(const TraceParams &p, const TraceBuffers &b, hipStream_t stream,

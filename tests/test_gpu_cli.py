@@ -76,6 +76,8 @@ def test_sequential_kernel_variants_write_identical_bytes(pkg, tmp_path, scene, 
     args = ["-w", "40", "-h", "28", "--spp", "5", "--seed", "11", "--scene", scene, "--raw", "--save-every", "0"] + extra
     variants = {"spec": {}, "reg": {"PTW_SEQ_SPEC": "0"}, "plain": {"PTW_SEQ_SPEC": "0", "PTW_SEQ_REG": "0"},
                 "spec_bands": {"PTW_STAGE_BUDGET_KB": "12"},
+                "gang8": {"PTW_SEQ_GANG": "8"}, "gang4_bands": {"PTW_SEQ_GANG": "4", "PTW_STAGE_BUDGET_KB": "12"},
+                "gang2": {"PTW_SEQ_GANG": "2"},
                 }
     exp = {"PTW_USE_EXPERIMENTS": "1"}
     if (pkg.LIB_PATH.parent / "experiments" / "libptw_hip.so").exists() and not extra:

@@ -74,7 +74,8 @@ TWO_MASTER_CASES = [
     (1400, "global", "traceSequential<4,6,global,stack,2 masters>"),   # tables exceed the LDS budget on their own
     (2000, "global", "traceSequential<6,6,global,stack,2 masters>"),
     (3000, "global", "traceSequential<9,6,global,stack,2 masters>"),
-    (4000, "global", "traceSequential<12,6,global,stack,2 masters>"),
+    (4000, "global", "traceSequential<11,6,global,stack,2 masters>"),
+    (4600, "global", "traceSequential<11,6,global,stack,2 masters>"),  # beyond 11 x 6 x 64 resident: the tail is streamed
 ]
 
 
@@ -408,3 +409,72 @@ def test_perpixel_kernel_is_chosen_by_a_timed_trial(pkg, name, want):
         assert st.trace_kernel.decode() == want
         assert st.samples == w * h * 64 and st.rays > 0      # the trial is not in the statistics
     assert int(cnt.min().item()) == 2 + 128 and int(cnt.max().item()) == 2 + 128
+
+
+# ---- several CUs per pass (traceSequentialGang) ---------------------------------------------------
+def _small_soup(pkg, ntri, nsph, shell, seed, w, h):
+    rng = np.random.default_rng(seed)
+    scene = pkg.Scene()
+    mats = [pkg.material("diffuse", rng.uniform(0.2, 0.9, 3)), pkg.material("light", rng.uniform(0.5, 3.0, 3)),
+            pkg.material("glossy", rng.uniform(0.2, 0.9, 3), 1.3, 20.0),
+            pkg.material("reflective", rng.uniform(0.2, 0.9, 3), 0.5, 4.0),
+            pkg.material("specular", rng.uniform(0.2, 0.9, 3), 1.0)]
+    for i in range(ntri):
+        c = rng.uniform(-2, 2, 3)
+        v = c + rng.uniform(-1.5, 1.5, (3, 3))
+        scene.add_triangle(v[0], v[1], v[2], mats[i % len(mats)])
+    for i in range(nsph):
+        scene.add_sphere(rng.uniform(-3, 3, 3), rng.uniform(0.1, 0.8), mats[(i + 2) % len(mats)])
+    if shell:
+        scene.add_sphere((0, 0, 0), 12.0, mats[0])
+    scene.set_environment_colour((0.3, 0.2, 0.1))
+    cam = pkg.set_focus(pkg.look_at((0, 0.5, 7), (0, 0, 0), (0, 1, 0), w, h, 45.0), (0, 0, 0), 0.02)
+    return scene, cam
+
+
+@pytest.mark.parametrize("groups", [2, 4, 8])
+@pytest.mark.parametrize("case", [
+    dict(scene="cornell", w=40, h=28, spp=5, over={}),
+    dict(scene="cornell", w=24, h=16, spp=9, over=dict(first_bounce_u=3, first_bounce_v=5), budget_kb=12),
+    dict(scene="single-sphere", w=24, h=16, spp=3, over=dict(max_depth=3)),
+    dict(soup=(33, 20, False), w=24, h=16, spp=4, over=dict(max_depth=8, first_bounce_u=2, first_bounce_v=2), budget_kb=12),
+    dict(soup=(64, 62, True), w=24, h=16, spp=2, over=dict(max_depth=4, first_bounce_u=1, first_bounce_v=7)),
+    dict(soup=(1, 0, True), w=16, h=12, spp=8, over=dict(max_depth=9)),
+])
+def test_gang_kernel_matches_oracle(pkg, ob, monkeypatch, groups, case):
+    """traceSequentialGang - 2, 4 or 8 CUs per pass, their 8 / 16 / 32 speculative candidates meeting
+    through global memory once per round - against the oracle: sums to 1e-12, every sample's RNG word
+    count exact; closed and open scenes, every depth, odd fan-outs, one pixel per round and many,
+    streams parked and resumed between bands."""
+    monkeypatch.setenv("PTW_SEQ_GANG", str(groups))
+    if case.get("budget_kb"):
+        monkeypatch.setenv("PTW_STAGE_BUDGET_KB", str(case["budget_kb"]))
+    w, h = case["w"], case["h"]
+    if "scene" in case:
+        scene = pkg.Scene()
+        cam = scene.build_named(case["scene"], w, h)
+    else:
+        scene, cam = _small_soup(pkg, *case["soup"], seed=4321 + groups, w=w, h=h)
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=case["spp"], seed=77, **case["over"])
+    ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(scene.view(), cam, params, threads=4)
+    rgb, cnt, words, variant, launches = _render_with_stats(pkg, scene, cam, params)
+    assert variant == f"traceSequentialGang<{groups} CUs per pass>", variant
+    if case.get("budget_kb"):
+        assert launches > 1
+    assert not np.isnan(rgb).any(), "a workgroup gave up waiting for its peers"
+    assert np.array_equal(cnt, ref_cnt)
+    assert np.array_equal(words, ref_words), "a path decision diverged from the oracle"
+    assert rel_err(rgb, ref_rgb) < TOL
+
+
+def test_gang_kernel_needs_every_workgroup_resident(pkg, monkeypatch):
+    """More passes than fit the device with 8 CUs each: the dispatcher falls back to the one-CU kernel
+    instead of launching workgroups that would wait for peers that are not running."""
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    monkeypatch.setenv("PTW_SEQ_GANG", "8")
+    scene = pkg.Scene()
+    cam = scene.build_named("cornell", 8, 6)
+    params = pkg.default_params(width=8, height=6, samples_per_pixel=cus // 8 + 1, seed=1)
+    *_, variant, _ = _render_with_stats(pkg, scene, cam, params)
+    assert variant == "traceSequentialSpec", variant
