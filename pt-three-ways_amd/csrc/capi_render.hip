@@ -395,6 +395,7 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   ctx.sampleQueue.reserve(1);
   b.sampleQueue = ctx.sampleQueue.ptr;
   b.specState = sequential ? ctx.specState.ptr : nullptr;
+#if PTW_EXPERIMENTS
   if (sequential && !ctx.countHist.ptr) {
     ctx.countHist.reserve(8);
     check(hipMemsetAsync(ctx.countHist.ptr, 0, 8 * sizeof(unsigned long long), stream), "memset");
@@ -403,10 +404,11 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
     ctx.wideCands.reserve(wideCandidateBytes());
     ctx.gangRecords.reserve(gangRecordBytes(npass));
   }
+#endif
   b.bvhNodes = ctx.bvhNodes.ptr;
   b.bvhLeafGeom = ctx.bvhLeafGeom.ptr;
   b.bvhLeafIndex = ctx.bvhLeafIndex.ptr;
-  b.countHist = ctx.countHist.ptr;
+  b.countHist = ctx.countHist.ptr;     // (these three: the experiments build only, null otherwise)
   b.wideCands = ctx.wideCands.ptr;
   b.gangRecords = ctx.gangRecords.ptr;
 

@@ -76,8 +76,6 @@ def test_sequential_kernel_variants_write_identical_bytes(pkg, tmp_path, scene, 
     args = ["-w", "40", "-h", "28", "--spp", "5", "--seed", "11", "--scene", scene, "--raw", "--save-every", "0"] + extra
     variants = {"spec": {}, "reg": {"PTW_SEQ_SPEC": "0"}, "plain": {"PTW_SEQ_SPEC": "0", "PTW_SEQ_REG": "0"},
                 "spec_bands": {"PTW_STAGE_BUDGET_KB": "12"},
-                "gang8": {"PTW_SEQ_GANG": "8"}, "gang4_bands": {"PTW_SEQ_GANG": "4", "PTW_STAGE_BUDGET_KB": "12"},
-                "gang2": {"PTW_SEQ_GANG": "2"},
                 }
     exp = {"PTW_USE_EXPERIMENTS": "1"}
     if (pkg.LIB_PATH.parent / "experiments" / "libptw_hip.so").exists() and not extra:
@@ -85,7 +83,9 @@ def test_sequential_kernel_variants_write_identical_bytes(pkg, tmp_path, scene, 
             "spec8": dict(exp, PTW_SEQ_SPEC8="1"), "spec8_bands": dict(exp, PTW_SEQ_SPEC8="1", PTW_STAGE_BUDGET_KB="12"),
             "wide8": dict(exp, PTW_SEQ_WIDE="1", PTW_WIDE_G="8"), "wide16": dict(exp, PTW_SEQ_WIDE="1", PTW_WIDE_G="16"),
             "wide8_few": dict(exp, PTW_SEQ_WIDE="1", PTW_WIDE_CANDIDATES="5"),
-            "wide_bands": dict(exp, PTW_SEQ_WIDE="1", PTW_STAGE_BUDGET_KB="12")})
+            "wide_bands": dict(exp, PTW_SEQ_WIDE="1", PTW_STAGE_BUDGET_KB="12"),
+            "gang8": dict(exp, PTW_SEQ_GANG="8"), "gang4_bands": dict(exp, PTW_SEQ_GANG="4", PTW_STAGE_BUDGET_KB="12"),
+            "gang2": dict(exp, PTW_SEQ_GANG="2")})
     blobs = {}
     for name, env in variants.items():
         run_cli(pkg, args + [str(tmp_path / f"{name}.raw")], ROOT, env=env)

@@ -411,8 +411,17 @@ def test_perpixel_kernel_is_chosen_by_a_timed_trial(pkg, name, want):
     assert int(cnt.min().item()) == 2 + 128 and int(cnt.max().item()) == 2 + 128
 
 
-# ---- several CUs per pass (traceSequentialGang) ---------------------------------------------------
-def _small_soup(pkg, ntri, nsph, shell, seed, w, h):
+# ---- several CUs per pass (traceSequentialGang; experiments build only) ---------------------------
+GANG_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+import numpy as np
+import torch
+import oracle_binding as ob
+pkg = ob.pkg
+TOL = 1e-12
+
+def small_soup(ntri, nsph, shell, seed, w, h):
     rng = np.random.default_rng(seed)
     scene = pkg.Scene()
     mats = [pkg.material("diffuse", rng.uniform(0.2, 0.9, 3)), pkg.material("light", rng.uniform(0.5, 3.0, 3)),
@@ -431,50 +440,68 @@ def _small_soup(pkg, ntri, nsph, shell, seed, w, h):
     cam = pkg.set_focus(pkg.look_at((0, 0.5, 7), (0, 0, 0), (0, 1, 0), w, h, 45.0), (0, 0, 0), 0.02)
     return scene, cam
 
-
-@pytest.mark.parametrize("groups", [2, 4, 8])
-@pytest.mark.parametrize("case", [
-    dict(scene="cornell", w=40, h=28, spp=5, over={}),
+CASES = [
+    dict(scene="cornell", w=40, h=28, spp=5, over={{}}),
     dict(scene="cornell", w=24, h=16, spp=9, over=dict(first_bounce_u=3, first_bounce_v=5), budget_kb=12),
     dict(scene="single-sphere", w=24, h=16, spp=3, over=dict(max_depth=3)),
     dict(soup=(33, 20, False), w=24, h=16, spp=4, over=dict(max_depth=8, first_bounce_u=2, first_bounce_v=2), budget_kb=12),
     dict(soup=(64, 62, True), w=24, h=16, spp=2, over=dict(max_depth=4, first_bounce_u=1, first_bounce_v=7)),
     dict(soup=(1, 0, True), w=16, h=12, spp=8, over=dict(max_depth=9)),
-])
-def test_gang_kernel_matches_oracle(pkg, ob, monkeypatch, groups, case):
-    """traceSequentialGang - 2, 4 or 8 CUs per pass, their 8 / 16 / 32 speculative candidates meeting
-    through global memory once per round - against the oracle: sums to 1e-12, every sample's RNG word
-    count exact; closed and open scenes, every depth, odd fan-outs, one pixel per round and many,
-    streams parked and resumed between bands."""
-    monkeypatch.setenv("PTW_SEQ_GANG", str(groups))
-    if case.get("budget_kb"):
-        monkeypatch.setenv("PTW_STAGE_BUDGET_KB", str(case["budget_kb"]))
-    w, h = case["w"], case["h"]
-    if "scene" in case:
-        scene = pkg.Scene()
-        cam = scene.build_named(case["scene"], w, h)
-    else:
-        scene, cam = _small_soup(pkg, *case["soup"], seed=4321 + groups, w=w, h=h)
-    params = pkg.default_params(width=w, height=h, samples_per_pixel=case["spp"], seed=77, **case["over"])
-    ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(scene.view(), cam, params, threads=4)
-    rgb, cnt, words, variant, launches = _render_with_stats(pkg, scene, cam, params)
-    assert variant == f"traceSequentialGang<{groups} CUs per pass>", variant
-    if case.get("budget_kb"):
-        assert launches > 1
-    assert not np.isnan(rgb).any(), "a workgroup gave up waiting for its peers"
-    assert np.array_equal(cnt, ref_cnt)
-    assert np.array_equal(words, ref_words), "a path decision diverged from the oracle"
-    assert rel_err(rgb, ref_rgb) < TOL
+]
+for groups in (2, 4, 8):
+    os.environ["PTW_SEQ_GANG"] = str(groups)
+    for case in CASES:
+        os.environ.pop("PTW_STAGE_BUDGET_KB", None)
+        if case.get("budget_kb"):
+            os.environ["PTW_STAGE_BUDGET_KB"] = str(case["budget_kb"])
+        w, h = case["w"], case["h"]
+        if "scene" in case:
+            scene = pkg.Scene(); cam = scene.build_named(case["scene"], w, h)
+        else:
+            scene, cam = small_soup(*case["soup"], seed=4321 + groups, w=w, h=h)
+        params = pkg.default_params(width=w, height=h, samples_per_pixel=case["spp"], seed=77, **case["over"])
+        ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(scene.view(), cam, params, threads=4)
+        ctx = pkg.Context(0); ctx.set_scene(scene); ctx.enable_stats(True)
+        rgb = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+        cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+        words = torch.zeros((case["spp"], h, w), dtype=torch.int32, device="cuda")
+        ctx.render(cam, params, rgb.data_ptr(), cnt.data_ptr(), words.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        st = ctx.stats(reset=True)
+        assert st.trace_kernel.decode() == f"traceSequentialGang<{{groups}} CUs per pass>", st.trace_kernel
+        assert not case.get("budget_kb") or st.trace_launches > 1
+        got = rgb.cpu().numpy()
+        assert not np.isnan(got).any(), "a workgroup gave up waiting for its peers"
+        assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), ref_cnt)
+        assert np.array_equal(words.cpu().numpy().astype(np.uint32), ref_words), "a path decision diverged"
+        assert float(np.max(np.abs(got - ref_rgb) / np.maximum(np.abs(ref_rgb), 1.0))) < TOL
+# more passes than fit the device with 8 CUs each: the one-CU kernel runs instead
+cus = torch.cuda.get_device_properties(0).multi_processor_count
+os.environ["PTW_SEQ_GANG"] = "8"
+scene = pkg.Scene(); cam = scene.build_named("cornell", 8, 6)
+params = pkg.default_params(width=8, height=6, samples_per_pixel=cus // 8 + 1, seed=1)
+ctx = pkg.Context(0); ctx.set_scene(scene); ctx.enable_stats(True)
+rgb = torch.zeros((6, 8, 3), dtype=torch.float64, device="cuda"); cnt = torch.zeros((6, 8), dtype=torch.int32, device="cuda")
+ctx.render(cam, params, rgb.data_ptr(), cnt.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+assert ctx.stats(reset=True).trace_kernel.decode() == "traceSequentialSpec"
+print("GANG_OK")
+"""
 
 
-def test_gang_kernel_needs_every_workgroup_resident(pkg, monkeypatch):
-    """More passes than fit the device with 8 CUs each: the dispatcher falls back to the one-CU kernel
-    instead of launching workgroups that would wait for peers that are not running."""
-    import torch
-    cus = torch.cuda.get_device_properties(0).multi_processor_count
-    monkeypatch.setenv("PTW_SEQ_GANG", "8")
-    scene = pkg.Scene()
-    cam = scene.build_named("cornell", 8, 6)
-    params = pkg.default_params(width=8, height=6, samples_per_pixel=cus // 8 + 1, seed=1)
-    *_, variant, _ = _render_with_stats(pkg, scene, cam, params)
-    assert variant == "traceSequentialSpec", variant
+def test_gang_kernel_matches_oracle(pkg, tmp_path):
+    """traceSequentialGang (experiments build: 2, 4 or 8 CUs per pass, their 8 / 16 / 32 speculative
+    candidates meeting through global memory once per round) against the oracle: sums to 1e-12, every
+    sample's RNG word count exact; closed and open scenes, every depth, odd fan-outs, streams parked
+    and resumed between bands; and the fallback when the workgroups would not all be resident.  The
+    kernel is not in the shipped library (it measured no faster than one CU per pass on the headline
+    scene), so the comparison runs in a child process on experiments/libptw_hip.so."""
+    from conftest import ROOT
+    lib = pkg.LIB_PATH.parent / "experiments" / "libptw_hip.so"
+    if not lib.exists():
+        pytest.skip("experiments library not built (make -C pt-three-ways_amd experiments)")
+    script = tmp_path / "gang.py"
+    script.write_text(GANG_SCRIPT.format(root=str(ROOT)))
+    proc = subprocess.run(["python", str(script)], env=dict(os.environ, PTW_LIB_PATH=str(lib)), capture_output=True,
+                          text=True, timeout=600)
+    assert proc.returncode == 0 and "GANG_OK" in proc.stdout, proc.stdout[-3000:] + proc.stderr[-3000:]
