@@ -11,7 +11,7 @@ from pathlib import Path
 
 src, dst = Path(sys.argv[1]), Path(sys.argv[2])
 dst.parent.mkdir(parents=True, exist_ok=True)
-OURS = ("traceSequentialSpec", "traceSequentialWide", "wideBuildCandidates", "traceSequential", "tracePerPixelBvh", "tracePerPixelPersistent", "tracePerPixel", "resolveKernel",
+OURS = ("traceSequentialSpec", "traceSequentialGang", "traceSequentialWide", "wideBuildCandidates", "traceSequential", "tracePerPixelBvh", "tracePerPixelPersistent", "tracePerPixel", "resolveKernel",
         "intersectBatch", "rngKat")
 
 
