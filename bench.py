@@ -315,9 +315,24 @@ def parity_vs_reference(pkg, ob, ctx, cam, view, scene_name, w, h, total_spp, se
     rgb = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
     cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
     words = torch.zeros((spp, h, w), dtype=torch.int32, device="cuda")
-    ctx.render(cam, params, rgb.data_ptr(), cnt.data_ptr(), words.data_ptr(),
-               torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
+    # The comparison must run the kernel variant the timed render ran.  The dispatcher picks the
+    # two-passes-per-workgroup form of the worker-wave kernels when there are more passes than CUs -
+    # true of the timed render of cfg3 / cfg4, not of a parity render of a few passes: ask for it.
+    cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    force_mm = total_spp > cus >= spp and view.num_triangles > 128 and "PTW_SEQ_MM" not in os.environ
+    if force_mm:
+        os.environ["PTW_SEQ_MM"] = "1"
+    try:
+        ctx.enable_stats(True)
+        ctx.stats(reset=True)
+        ctx.render(cam, params, rgb.data_ptr(), cnt.data_ptr(), words.data_ptr(),
+                   torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        parity_kernel = ctx.stats(reset=True).trace_kernel.decode()
+        ctx.enable_stats(False)
+    finally:
+        if force_mm:
+            del os.environ["PTW_SEQ_MM"]
     gpu_sum = rgb.cpu().numpy()[:rows_end]
     gpu_cnt = cnt.cpu().numpy().astype(np.uint32)[:rows_end]
 
@@ -356,7 +371,7 @@ def parity_vs_reference(pkg, ob, ctx, cam, view, scene_name, w, h, total_spp, se
         "samples_word_count_differs": stats["word_mismatch"], "samples": nsamp,
         "word_count_differences": stats["where"],
         "counts_equal": bool(np.all(gpu_cnt == spp)),
-        "parity_passes": spp,
+        "parity_passes": spp, "parity_kernel": parity_kernel,
         "parity_note": f"{where}, passes [0, {spp}) of the {total_spp} (seeds {seed}..{seed + spp - 1}); all 256 "
                        "passes of the headline frame: profiles/ (the round's *_full_parity.json)",
         "mean_words_per_sample": stats["words_total"] / float(nsamp),

@@ -45,6 +45,22 @@ if trace_db:
         if short(name):
             stats[short(name)] = {"calls": calls, "total_ms": total / 1e3, "avg_ms": avg / 1e3}
     lines.append("")
+    # every call of the radiance kernels, in launch order (an average over launches of different
+    # sizes - timed steps, parity renders, warm-ups - says little)
+    try:
+        per = {}
+        for name, ms in con.execute("select name, (end - start) / 1e6 from kernels order by start"):
+            k = short(name)
+            if k and k.startswith("trace"):
+                per.setdefault(k, []).append(ms)
+        lines += ["## every launch of the radiance kernels (ms, launch order)", ""]
+        for k, v in per.items():
+            if len(v) <= 12:
+                lines.append(f"* `{k}`: " + ", ".join(f"{x:.3f}" for x in v))
+                stats.setdefault(k, {})["launch_ms"] = v
+        lines.append("")
+    except sqlite3.Error:
+        pass
 
 pmc = {}
 for d in sorted(src.glob("pmc*")):
