@@ -245,6 +245,7 @@ __device__ __forceinline__ d3 radiance0(CTX &ctx, const TraceParams &p, const Tr
   // lanes of the kernel-argument tuple for every sub-sample)
   double invU = p.invU, invV = p.invV;
   asm volatile("" : "+v"(invU), "+v"(invV));
+  if constexpr (CTX::kLookAhead) ctx.setLookAheadFrame(s, d, invU, invV);
   for (int uS = 0; uS < p.fbU; ++uS) {
     for (int vS = 0; vS < p.fbV; ++vS) {
       const unsigned long long tB0 = ctx.now();
@@ -266,10 +267,22 @@ __device__ __forceinline__ d3 radiance0(CTX &ctx, const TraceParams &p, const Tr
       if constexpr (CTX::kLookAhead) {
         int nu = uS, nv = vS + 1;
         if (nv == p.fbV) nv = 0, ++nu;
-        ctx.armLookAhead(nu < p.fbU, s, d, nu, nv, invU, invV);
+        ctx.armLookAhead(nu < p.fbU, nu, nv);
       }
       ctx.acc(3, tA0, nd.x);
-      d3 child = ctx.runChain(p, triShade, spheres, s.pos, nd);
+      d3 child;
+      if constexpr (CTX::kMasterChain) {
+        // (worker-wave masters: the sub-sample whose first ray leaves the scene - most of them in an
+        // open scene - costs the pick of the workers' answers, one branch and this sum)
+        if (p.maxDepth <= 1) {
+          child = mk(0, 0, 0);
+        } else {
+          const HitKey k1 = ctx.intersect(s.pos, nd);
+          child = uniformBool(k1.idx == kMiss) ? ctx.envColour : ctx.chainMasterFrom(p, s.pos, nd, k1);
+        }
+      } else {
+        child = ctx.runChain(p, triShade, spheres, s.pos, nd);
+      }
       const unsigned long long tR0 = ctx.now();
       result = result + (refl ? s.emission + child : s.emission + s.diffuse * child);
       ctx.acc(7, tR0, result.x);
@@ -292,12 +305,15 @@ struct SeqShared {
   double hemi[kMtDoubles][3];
 };
 
-struct PartialHit {
+// A worker wave's answer: its nearest hit.  16 bytes, one ds_read_b128 for the master: the distance
+// and the combined primitive index with the only fact ever used of the determinant - the sign test
+// `det < epsilon` of Scene.cpp:107 - in bit 31 (kMiss, all ones, with t = +inf for "nothing hit").
+struct alignas(16) PartialHit {
   double t;
-  double det;
-  uint32_t idx;
+  uint32_t idxSign;
   uint32_t pad;
 };
+constexpr size_t kSeqCmdBytes = 128; // the masters' commands (56 bytes each) behind the answers
 
 // Master -> worker request of the multi-wave sequential kernel.
 constexpr uint32_t kCmdTrace = 1, kCmdExit = 2;
@@ -373,8 +389,10 @@ struct SeqCtx {
   // the master is looking at right now: it is evaluated in that idle time, and taken if the
   // position still matches when the next sub-sample starts (lookAhead / takeLookAhead).
   static constexpr bool kLookAhead = WAVES > 1;
-  Surface laSurf;  // look-ahead inputs: the first-bounce surface, the incoming direction, ...
-  d3 laDir;
+  // two masters per workgroup: radiance0 and the chain use chainMaster / chainMasterFrom
+  static constexpr bool kMasterChain = PTW_SEQ_CHAIN_MASTER && WAVES > 1 && MASTERS == 2;
+  Surface laSurf;  // look-ahead inputs: the first-bounce surface, the incoming direction (set once per
+  d3 laDir;        // pixel, before the fan-out: inside its loop they are the caller's own values), ...
   double laInvU, laInvV;
   int laU, laV;    // ... the stratum of the next sub-sample
   bool laArmed;
@@ -425,6 +443,7 @@ struct SeqCtx {
   unsigned parity;
 #if PTW_PROFILE_PHASES
   unsigned long long prof[12];
+  unsigned long long mprof[6]; // master, inside intersect(): publish, wait B1, shadow work, wait B2, pick
 #endif
 
   // Triangle held in slot s of this lane.  WAVES == 1: slot-major (slot s of all lanes covers
@@ -707,10 +726,12 @@ struct SeqCtx {
     return key;
   }
 
-  __device__ __forceinline__ void armLookAhead(bool on, const Surface &s, d3 dirIn, int nu, int nv,
-                                               double invU, double invV) {
+  __device__ __forceinline__ void setLookAheadFrame(const Surface &s, d3 dirIn, double invU, double invV) {
+    laSurf = s, laDir = dirIn, laInvU = invU, laInvV = invV;
+  }
+  __device__ __forceinline__ void armLookAhead(bool on, int nu, int nv) {
     laArmed = on && (laMisses < 2 || (++laTick & 7u) == 0);
-    laSurf = s, laDir = dirIn, laU = nu, laV = nv, laInvU = invU, laInvV = invV;
+    laU = nu, laV = nv;
   }
   __device__ __forceinline__ void lookAhead() {
     laPos = -1;
@@ -755,17 +776,18 @@ struct SeqCtx {
     PartialHit ph[WAVES];
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) ph[w] = partials[w];
-    double bt = ph[0].t, bdet = ph[0].det;
-    uint32_t bi = ph[0].idx;
+    double bt = ph[0].t;
+    uint32_t bw = ph[0].idxSign;
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) {
-      const bool take = (ph[w].t < bt) | ((ph[w].t == bt) & (ph[w].idx < bi));
+      const bool take = (ph[w].t < bt) | ((ph[w].t == bt) & ((ph[w].idxSign & 0x7fffffffu) < (bw & 0x7fffffffu)));
       bt = take ? ph[w].t : bt;
-      bdet = take ? ph[w].det : bdet;
-      bi = take ? ph[w].idx : bi;
+      bw = take ? ph[w].idxSign : bw;
     }
     HitKey key;
-    key.t = bt, key.idx = bi, key.det = bdet;
+    key.t = bt;
+    key.idx = bw == kMiss ? kMiss : (bw & 0x7fffffffu);
+    key.det = (bw >> 31) ? -1.0 : 1.0; // (only its sign test is ever used)
     return key;
   }
 
@@ -783,11 +805,24 @@ struct SeqCtx {
       cmd->d[0] = d.x, cmd->d[1] = d.y, cmd->d[2] = d.z;
       if (MASTERS == 1) cmd->op = kCmdTrace;
     }
+#if PTW_PROFILE_PHASES
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    PTW_T(tMa);
     ldsBarrier(); // B1: ray visible to the workers
+    PTW_T(tMb);
     // the search takes a thousand cycles and more: the stack entry of the level just left ...
     flushPending();
     if (laArmed) lookAhead(); // ... and the next sub-sample's first-bounce scatter
+#if PTW_PROFILE_PHASES
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    PTW_T(tMc);
     ldsBarrier(); // B2: partial results visible
+    PTW_T(tMd);
+#if PTW_PROFILE_PHASES
+    mprof[0] += tMa - tM0, mprof[1] += tMb - tMa, mprof[2] += tMc - tMb, mprof[3] += tMd - tMc;
+#endif
     // (MASTERS == 2: the same two barriers - the workers search this ray between them, and the
     // other master's ray between B2 and this master's next B1, i.e. while this one shades)
     if (MASTERS == 2) tick += 2;
@@ -799,12 +834,18 @@ struct SeqCtx {
     uint32_t cidx = kMiss;
     if ((threadIdx.x & 63) < WAVES) {
       const PartialHit ph = partials[threadIdx.x & 63];
-      ct = ph.t, cidx = ph.idx, cdet = ph.det;
+      ct = ph.t, cidx = ph.idxSign == kMiss ? kMiss : (ph.idxSign & 0x7fffffffu), cdet = (ph.idxSign >> 31) ? -1.0 : 1.0;
     }
     const HitKey key = pickNearest(ct, cidx, cdet);
 #endif
+#if PTW_PROFILE_PHASES
+    asm volatile("" : "+v"(const_cast<HitKey &>(key).t));
+#endif
     PTW_T(tM1);
     PTW_ACC(5, tM0, tM1);
+#if PTW_PROFILE_PHASES
+    mprof[4] += tM1 - tMd;
+#endif
     return key;
   }
 
@@ -833,7 +874,8 @@ struct SeqCtx {
         const HitKey found = localNearest(o, d);
         if ((tid & 63) == 0) {
           PartialHit ph;
-          ph.t = found.t, ph.det = found.det, ph.idx = found.idx, ph.pad = 0;
+          ph.t = found.t, ph.pad = 0;
+          ph.idxSign = found.idx == kMiss ? kMiss : (found.idx | (found.det < kEpsilon ? 0x80000000u : 0u));
           partials[(n & 1) * WAVES + (tid >> 6)] = ph;
         }
 #if PTW_PROFILE_PHASES
@@ -849,7 +891,8 @@ struct SeqCtx {
       const HitKey mine = localNearest(o, d);
       if ((tid & 63) == 0) {
         PartialHit ph;
-        ph.t = mine.t, ph.det = mine.det, ph.idx = mine.idx, ph.pad = 0;
+        ph.t = mine.t, ph.pad = 0;
+        ph.idxSign = mine.idx == kMiss ? kMiss : (mine.idx | (mine.det < kEpsilon ? 0x80000000u : 0u));
         partials[tid >> 6] = ph;
       }
 #if PTW_PROFILE_PHASES
@@ -1036,14 +1079,21 @@ struct SeqCtx {
   // left to flushPending(), which runs while the workers search the NEXT ray.  Everything else
   // takes the general code, which is the sequence radianceChain() runs.
   __device__ __forceinline__ d3 chainMaster(const TraceParams &tp, d3 o, d3 d) {
+    if (tp.maxDepth <= 1) return mk(0, 0, 0); // Scene.cpp:128 at depth 1
+    const HitKey k = intersect(o, d);
+    if (uniformBool(k.idx == kMiss)) return envColour; // Scene.cpp:131-133
+    return chainMasterFrom(tp, o, d, k);
+  }
+  // ... from the first hit `k` of the ray (o, d) on (not a miss: the fan-out loop of radiance0 deals
+  // with the sub-sample whose first ray leaves the scene - four of five on suzanne - itself, in a
+  // handful of instructions).
+  __device__ __forceinline__ d3 chainMasterFrom(const TraceParams &tp, d3 o, d3 d, HitKey k) {
     int nlev = 0;
     d3 L;
     const int maxDepth = tp.maxDepth;
     const uint32_t nsph = tp.nsph, ntri = tp.ntri;
-    if (maxDepth <= 1) return mk(0, 0, 0); // Scene.cpp:128 at depth 1
     int depth = 1;
-    for (;;) {
-      const HitKey k = intersect(o, d);
+    for (;; k = intersect(o, d)) {
       const int notLast = depth + 1 - maxDepth;   // < 0
       const int inBlock = pos + 2 - kMtDoubles;   // < 0  <=>  pos + 3 <= kMtDoubles
       const bool isTri = (k.idx - nsph) < ntri;   // unsigned: kMiss and spheres fail
@@ -1268,7 +1318,7 @@ __host__ __device__ inline size_t seqLdsBytes(int waves, int maxDepth, bool ldsT
                                               uint32_t nmat, uint32_t nsph, int masters = 1) {
   size_t n = masters * sizeof(SeqShared);
   n += static_cast<size_t>(waves) * (maxDepth > 0 ? maxDepth : 1) * sizeof(Level);
-  n += (masters + 1) * static_cast<size_t>(waves) * sizeof(PartialHit);
+  n += masters * static_cast<size_t>(waves) * sizeof(PartialHit) + kSeqCmdBytes;
   n = (n + 63) & ~static_cast<size_t>(63);
   if (ldsTables) {
     n += static_cast<size_t>(nsph) * sizeof(SphereRec);
@@ -1294,7 +1344,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
   Level *stacks = reinterpret_cast<Level *>(ldsRaw + MASTERS * sizeof(SeqShared));
   PartialHit *partials = reinterpret_cast<PartialHit *>(stacks + WAVES * depthSlots);
   size_t off = MASTERS * sizeof(SeqShared) + static_cast<size_t>(WAVES) * depthSlots * sizeof(Level) +
-               (MASTERS + 1) * static_cast<size_t>(WAVES) * sizeof(PartialHit);
+               MASTERS * static_cast<size_t>(WAVES) * sizeof(PartialHit) + kSeqCmdBytes;
   off = (off + 63) & ~static_cast<size_t>(63);
 
   const int pass = blockIdx.x * MASTERS + master;
@@ -1332,7 +1382,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
                                                         : workerRank * p.seqUnitsA);
   }
   ctx.stack = stacks + master * depthSlots; // only the master waves use a radiance stack
-  // [MASTERS][WAVES] partial results, then the commands (56 B each) in the spare WAVES entries
+  // [MASTERS][WAVES] partial results, then the commands (56 B each)
   ctx.allCmds = reinterpret_cast<SeqCommand *>(partials + MASTERS * WAVES);
   ctx.partials = isWorker ? partials : partials + master * WAVES;
   ctx.cmd = ctx.allCmds + master;
@@ -1342,7 +1392,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
   ctx.laMisses = 0;
   ctx.laTick = 0;
   ctx.pendKind = 0;
-  static_assert(MASTERS * sizeof(SeqCommand) <= WAVES * sizeof(PartialHit) || WAVES == 1, "commands fit");
+  static_assert(MASTERS * sizeof(SeqCommand) <= kSeqCmdBytes, "commands fit");
   ctx.words = 0;
   ctx.rays = 0;
   ctx.parity = 0;
@@ -1406,6 +1456,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
   double *myStage = stage + static_cast<size_t>(pass) * p.pixCount * 3;
 #if PTW_PROFILE_PHASES
   for (int i = 0; i < 12; ++i) ctx.prof[i] = 0;
+  for (int i = 0; i < 6; ++i) ctx.mprof[i] = 0;
   const unsigned long long tStart = __builtin_amdgcn_s_memtime();
 #endif
   for (uint32_t i = 0; i < p.pixCount; ++i) {
@@ -1444,6 +1495,11 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
            ctx.prof[8] / r, ctx.prof[9] / r, ctx.prof[10] / r, ctx.prof[11] / r,
            ((tEnd - tStart) - ctx.prof[0] - ctx.prof[1] - ctx.prof[2] - ctx.prof[3] - ctx.prof[5] -
             ctx.prof[6] - ctx.prof[7] - ctx.prof[8] - ctx.prof[10] - ctx.prof[11]) / r);
+    if (WAVES > 1)
+      printf("MASTER per ray, inside intersect(): publish=%.0f waitB1=%.0f shadow(flush+lookahead)=%.0f waitB2=%.0f pick=%.0f; "
+             "outside intersect()=%.0f\n",
+             ctx.mprof[0] / r, ctx.mprof[1] / r, ctx.mprof[2] / r, ctx.mprof[3] / r, ctx.mprof[4] / r,
+             ((tEnd - tStart) - ctx.prof[5]) / r);
   }
 #endif
   ctx.stopWorkers();
@@ -1899,6 +1955,7 @@ constexpr int kBvhStack = 32;
 template <bool BVH>
 struct PixCtxT {
   static constexpr bool kLookAhead = false; // (radiance0: a lane never waits for anybody here)
+  static constexpr bool kMasterChain = false;
   const TraceParams *p;
   const double *triGeom;
   const TriShade *triShade;
