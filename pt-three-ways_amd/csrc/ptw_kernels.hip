@@ -2134,13 +2134,17 @@ struct PixCtxT {
 using PixCtx = PixCtxT<false>;
 
 constexpr int kPixBlock = 256;
-// resident waves per SIMD the PERPIXEL kernels are compiled for (A/B: -DPTW_PIX_WAVES=n)
+// resident waves per SIMD the lock-step PERPIXEL kernel is compiled for (A/B: -DPTW_PIX_WAVES=n)
 #ifndef PTW_PIX_WAVES
-#define PTW_PIX_WAVES 3
+#define PTW_PIX_WAVES 4
 #endif
 
-// Lock-step kernel: 3 waves per SIMD (157 VGPRs, nothing spilled).  With the triangles in SGPRs the
-// loop has no latency left to hide, and 4 waves (128 VGPRs, 160 B/lane of scratch) measured the same.
+// Lock-step kernel.  Unconstrained it needs 174 VGPRs (two waves per SIMD); measured with the
+// grid-stride loop on Cornell 1024 x 1024 @ 256 (profiles/r03i_lockstep_waves_per_simd.txt): 2 waves
+// 180, 3 waves (168 VGPRs, 5 spilled) 224, **4 waves (128 VGPRs, 80 spilled, 224 B/lane of scratch)
+// 243**, 5 waves 244, 6 waves (80 VGPRs, 152 spilled) 246 Msamples/s - occupancy buys more than the
+// spills cost (the first-bounce surface, 54 registers, is only touched between chains), and flattens
+// out at four.  (Round 2 measured 3 = 4 on the one-sample-per-lane form of this kernel.)
 template <bool BVH>
 __device__ __forceinline__ void perPixelSample(const TraceParams &p, const TraceBuffers &b, uint32_t *ldsWords) {
   const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;

@@ -39,8 +39,8 @@ for c in cfg3 cfg4; do
 done
 cd $REPO
 ls -la $OUT
-# 5) the metric's second half over ALL 256 passes (13 minutes of host work)
-( timeout 2400 python bench.py --parity-passes 0 --no-cpu-baseline --no-secondary --no-other-configs --no-strict > $OUT/bench_full_parity.json 2> $OUT/bench_full_parity.err; echo "rc=$?" >> $OUT/bench_full_parity.err )
+# 5) the metric's second half over ALL 256 passes (13 minutes of host work; SKIP_FULL_PARITY=1 skips it)
+[ -n "$SKIP_FULL_PARITY" ] || ( timeout 2400 python bench.py --parity-passes 0 --no-cpu-baseline --no-secondary --no-other-configs --no-strict > $OUT/bench_full_parity.json 2> $OUT/bench_full_parity.err; echo "rc=$?" >> $OUT/bench_full_parity.err )
 python - <<'PY'
 import json
 try:
