@@ -2138,13 +2138,62 @@ constexpr int kPixBlock = 256;
 #ifndef PTW_PIX_WAVES
 #define PTW_PIX_WAVES 4
 #endif
+// lock-step kernel: rebuild the first-bounce surface per sub-sample (radiance0Pix) instead of carrying it
+#ifndef PTW_PIX_REBUILD
+#define PTW_PIX_REBUILD 1
+#endif
 
-// Lock-step kernel.  Unconstrained it needs 174 VGPRs (two waves per SIMD); measured with the
-// grid-stride loop on Cornell 1024 x 1024 @ 256 (profiles/r03i_lockstep_waves_per_simd.txt): 2 waves
-// 180, 3 waves (168 VGPRs, 5 spilled) 224, **4 waves (128 VGPRs, 80 spilled, 224 B/lane of scratch)
-// 243**, 5 waves 244, 6 waves (80 VGPRs, 152 spilled) 246 Msamples/s - occupancy buys more than the
-// spills cost (the first-bounce surface, 54 registers, is only touched between chains), and flattens
-// out at four.  (Round 2 measured 3 = 4 on the one-sample-per-lane form of this kernel.)
+// Lock-step kernel.  With the first-bounce surface carried through the fan-out it needs 174 VGPRs
+// (two waves per SIMD); measured in that form with the grid-stride loop on Cornell 1024 x 1024 @ 256
+// (profiles/r03i_lockstep_waves_per_simd.txt): 2 waves 180, 3 waves (168 VGPRs, 5 spilled) 224,
+// **4 waves (128 VGPRs, 80 spilled) 243**, 5 waves 244, 6 waves (80 VGPRs, 152 spilled) 246
+// Msamples/s - occupancy buys more than spills cost, and flattens out at four.  The shipped form
+// rebuilds the surface per sub-sample (radiance0Pix below) and spills 10 registers at four waves.
+// (Round 2 measured 3 = 4 on the one-sample-per-lane form of this kernel.)
+// radiance0() for the lock-step PERPIXEL kernel with the first-bounce surface REBUILT for every
+// sub-sample instead of carried through the fan-out: a Surface is 27 doubles, live across sixteen
+// chains, and the kernel runs at four waves per SIMD (128 registers).  What survives a chain is the
+// hit (distance, index, determinant) and the primary ray; the surface is re-derived from the tables
+// before the scatter and its two colours are re-read after the chain - the same loads and the same
+// arithmetic on the same inputs, so the same values.  (The empty asm statements keep the compiler
+// from hoisting the rebuild out of the loop, which would bring the 54 registers back.)
+// Measured against the carried surface (make alt ALT_FLAGS=-DPTW_PIX_REBUILD=0;
+// profiles/r03j_lockstep_rebuild_surface_ab.txt): 10 spilled registers instead of 80, 67 instead of
+// 548 B of HBM traffic per sample (24 are the algorithmic ones), Cornell 240.5 against 243.0,
+// suzanne 21.0 against 21.6, single-sphere 313 against 304 Msamples/s.
+template <bool BVH>
+__device__ __forceinline__ d3 radiance0Pix(PixCtxT<BVH> &ctx, const TraceParams &p, const TriShade *triShade,
+                                           const SphereRec *spheres, d3 o, d3 d) {
+  if (p.maxDepth <= 0) return mk(0, 0, 0);
+  HitKey k = ctx.intersect(o, d);
+  if (k.idx == kMiss) return ld3(p.env);
+  if (p.preview) return makeSurface(p, triShade, spheres, k, o, d).diffuse; // Scene.cpp:137-138
+  d3 result = mk(0, 0, 0);
+  for (int uS = 0; uS < p.fbU; ++uS) {
+    for (int vS = 0; vS < p.fbV; ++vS) {
+      d3 nd, from;
+      bool refl;
+      {
+        asm volatile("" : "+v"(k.t));
+        const Surface s = makeSurface(p, triShade, spheres, k, o, d);
+        double xu, xv, pd;
+        ctx.draw3(xu, xv, pd);
+        double u, v;
+        stratify(p, uS, vS, xu, xv, p.invU, p.invV, u, v);
+        refl = scatter(ctx, s, d, u, v, pd, nd);
+        from = s.pos;
+      }
+      const d3 child = ctx.runChain(p, triShade, spheres, from, nd);
+      asm volatile("" : "+v"(k.idx));
+      const double *m = k.idx >= p.nsph ? triShade[k.idx - p.nsph].emission : spheres[k.idx].emission;
+      const double *df = k.idx >= p.nsph ? triShade[k.idx - p.nsph].diffuse : spheres[k.idx].diffuse;
+      const d3 emission = ld3(m), diffuse = ld3(df);
+      result = result + (refl ? emission + child : emission + diffuse * child);
+    }
+  }
+  return result * p.invFirstBounce; // Vec3::operator/(double): multiply by 1.0 / (nU * nV)
+}
+
 template <bool BVH>
 __device__ __forceinline__ void perPixelSample(const TraceParams &p, const TraceBuffers &b, uint32_t *ldsWords) {
   const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
@@ -2183,7 +2232,11 @@ __device__ __forceinline__ void perPixelSample(const TraceParams &p, const Trace
   }
   d3 o, d;
   cameraRay(p.cam, px, py, r0, r1, r2, r3, o, d);
+#if PTW_PIX_REBUILD
+  const d3 L = radiance0Pix(ctx, p, b.triShade, b.spheres, o, d);
+#else
   const d3 L = radiance0(ctx, p, b.triShade, b.spheres, o, d);
+#endif
   double *out = b.stage + (static_cast<size_t>(pass) * p.pixCount + i) * 3;
   out[0] = L.x, out[1] = L.y, out[2] = L.z;
   if (b.words) b.words[static_cast<size_t>(pass) * p.npix + pix] = ctx.words;
