@@ -126,8 +126,12 @@ typedef struct ptw_render_params {
 } ptw_render_params;
 
 /* Progress callback, the analogue of `updateFunc(output)` (src/dod/Scene.cpp:245) and of
- * Progressifier (src/util/Progressifier.cpp:11-21): called on the calling thread between
- * device launches with the number of finished samples.  Return non-zero to cancel. */
+ * Progressifier (src/util/Progressifier.cpp:11-21): called between device launches with the
+ * number of finished samples - on the calling thread for single-device renders; with
+ * ptw_render_options.num_devices > 1 from the host thread that drives the first device, while the
+ * calling thread waits for it (never concurrently with itself).  Return non-zero to cancel: the
+ * render ends with PTW_ERR_INVALID ("cancelled by the callback"), every shard stopping at its next
+ * band and none entering the collective. */
 typedef int (*ptw_progress_fn)(void *user, uint64_t samples_done, uint64_t samples_total);
 /* The full form of `updateFunc(output)` (src/dod/Scene.cpp:245, used by src/main/main.cpp:331-343
  * for --save-every): called on the calling thread between device launches with the caller's
