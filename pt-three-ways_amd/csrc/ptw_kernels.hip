@@ -2266,7 +2266,8 @@ __global__ __launch_bounds__(kPixBlock) void tracePerPixelBvh(const TraceParams 
 // up the next sample instead of idling until the slowest lane of the wave is done.
 // Triangles are streamed with wave-uniform scalar loads, double-buffered one triangle ahead
 // so the SMEM latency hides behind the ~45 VALU instructions of a Moller-Trumbore test.
-// The default for every scene (launchTracePerPixel); 128 VGPRs at 4 waves per SIMD.
+// The kernel for open scenes and for small renders (launchTracePerPixel; capi_render.hip times it
+// against the lock-step kernel once per scene); 128 VGPRs at 4 waves per SIMD.
 // -----------------------------------------------------------------------------------------
 constexpr int kPix2Block = 256;
 
