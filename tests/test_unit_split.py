@@ -1,0 +1,56 @@
+"""CPU: seqUnitSplit (csrc/ptw_kernels.h) - how the worker-wave kernels hand a scene's units of 64
+triangles to their worker waves.  Compiled as host code with hipcc (no device needed): every
+triangle that fits the register file is resident exactly once, no share exceeds the cap, and what
+does not fit is left to the streamed tail."""
+import subprocess
+import textwrap
+
+import pytest
+
+PROGRAM = textwrap.dedent(r"""
+    #include "ptw_kernels.h"
+    #include <cstdio>
+    int main() {
+      long checked = 0;
+      for (int masters = 1; masters <= 2; ++masters) {
+        const int nB = masters, nA = (masters == 2 ? 6 : 7) - masters;
+        for (int ratio : {25, 60, 100, 150, 200, 400})
+          for (int cap : {1, 2, 3, 4, 6, 9, 11, 12})
+            for (unsigned ntri = 129; ntri <= 6000; ntri += (ntri < 1500 ? 1 : 37)) {
+              int uA = -1, uB = -1;
+              ptw::seqUnitSplit(ntri, nA, nB, ratio, cap, uA, uB);
+              const int U = (ntri + 63) / 64;
+              if (uA < 0 || uB < 0 || uA > cap || uB > cap) { std::printf("share out of range %u %d %d\n", ntri, uA, uB); return 1; }
+              const int resident = nA * uA + nB * uB;
+              // either the whole scene is resident, or every wave holds as much as the cap allows on
+              // at least one side and the rest is streamed
+              if (resident < U && uA < cap && uB < cap) { std::printf("lost triangles: ntri %u ratio %d cap %d -> %d + %d\n", ntri, ratio, cap, uA, uB); return 1; }
+              // no more than one spare unit per A wave beyond what the scene needs
+              if (resident >= U && resident - U > nA + nB) { std::printf("wasteful: ntri %u ratio %d cap %d -> %d x %d + %d x %d for %d\n", ntri, ratio, cap, nA, uA, nB, uB, U); return 1; }
+              ++checked;
+            }
+      }
+      // the defaults of the shipped dispatcher: equal shares
+      int uA, uB;
+      ptw::seqUnitSplit(970, 4, 2, 100, 11, uA, uB);   // suzanne: 16 units
+      if (uA != 3 || uB != 3) { std::printf("suzanne %d %d\n", uA, uB); return 1; }
+      ptw::seqUnitSplit(3442, 4, 2, 100, 11, uA, uB);  // ce: 54 units
+      if (uA != 9 || uB != 9) { std::printf("ce %d %d\n", uA, uB); return 1; }
+      std::printf("OK %ld\n", checked);
+      return 0;
+    }
+""")
+
+
+def test_unit_split_covers_the_scene(tmp_path):
+    from conftest import ROOT
+    src = tmp_path / "split.cpp"
+    src.write_text(PROGRAM)
+    exe = tmp_path / "split"
+    build = subprocess.run(["hipcc", "-std=c++17", "-O1", "-x", "hip", "--offload-arch=gfx950",
+                            f"-I{ROOT / 'pt-three-ways_amd' / 'csrc'}", str(src), "-o", str(exe)],
+                           capture_output=True, text=True, timeout=300)
+    if build.returncode != 0:
+        pytest.skip("hipcc cannot build a host program here: " + build.stderr[-400:])
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and run.stdout.startswith("OK"), run.stdout + run.stderr
