@@ -236,6 +236,7 @@ template <typename CTX>
 __device__ __forceinline__ d3 radiance0(CTX &ctx, const TraceParams &p, const TriShade *triShade,
                                         const SphereRec *spheres, d3 o, d3 d) {
   if (p.maxDepth <= 0) return mk(0, 0, 0);
+  ctx.markRay(0);
   const HitKey k = ctx.intersect(o, d);
   if (ctx.branch(k.idx == kMiss)) return ld3(p.env);
   const Surface s = ctx.surfaceAt(k, o, d);
@@ -277,6 +278,7 @@ __device__ __forceinline__ d3 radiance0(CTX &ctx, const TraceParams &p, const Tr
         if (p.maxDepth <= 1) {
           child = mk(0, 0, 0);
         } else {
+          ctx.markRay(1);
           const HitKey k1 = ctx.intersect(s.pos, nd);
           child = uniformBool(k1.idx == kMiss) ? ctx.envColour : ctx.chainMasterFrom(p, s.pos, nd, k1);
         }
@@ -444,6 +446,11 @@ struct SeqCtx {
 #if PTW_PROFILE_PHASES
   unsigned long long prof[12];
   unsigned long long mprof[6]; // master, inside intersect(): publish, wait B1, shadow work, wait B2, pick
+  // master, OUTSIDE intersect(): cycles from one answer to the next published ray, by what the answer
+  // was: [ray kind 0 primary / 1 first ray of a sub-sample / 2 deeper][0 hit / 1 miss]
+  // (six scalars, not an array: a run-time index would put it in scratch memory and ruin the timing)
+  unsigned long long g00, g01, g10, g11, g20, g21, n00, n01, n10, n11, n20, n21, lastExit;
+  int rayKind, lastKind, lastMiss;
 #endif
 
   // Triangle held in slot s of this lane.  WAVES == 1: slot-major (slot s of all lanes covers
@@ -800,6 +807,18 @@ struct SeqCtx {
     rays++;
     if (WAVES == 1) return localNearest(o, d);
     PTW_T(tM0);
+#if PTW_PROFILE_PHASES
+    if (lastExit) {
+      const unsigned long long gap = tM0 - lastExit;
+      const int which = lastKind * 2 + lastMiss;
+      if (which == 0) g00 += gap, n00++;
+      if (which == 1) g01 += gap, n01++;
+      if (which == 2) g10 += gap, n10++;
+      if (which == 3) g11 += gap, n11++;
+      if (which == 4) g20 += gap, n20++;
+      if (which == 5) g21 += gap, n21++;
+    }
+#endif
     if ((threadIdx.x & 63) == 0) { // (the master wave's first lane; cmd / partials are this master's)
       cmd->o[0] = o.x, cmd->o[1] = o.y, cmd->o[2] = o.z;
       cmd->d[0] = d.x, cmd->d[1] = d.y, cmd->d[2] = d.z;
@@ -845,6 +864,8 @@ struct SeqCtx {
     PTW_ACC(5, tM0, tM1);
 #if PTW_PROFILE_PHASES
     mprof[4] += tM1 - tMd;
+    lastKind = rayKind, lastMiss = key.idx == kMiss ? 1 : 0, lastExit = __builtin_amdgcn_s_memtime();
+    rayKind = 2; // (whoever traces a primary ray or a sub-sample's first ray says so before the call)
 #endif
     return key;
   }
@@ -1008,12 +1029,14 @@ struct SeqCtx {
     return pd < reflectance(s.normal, dirIn, s.iorFrom, s.iorTo, s.iorRatio);
   }
 #if PTW_PROFILE_PHASES
+  __device__ __forceinline__ void markRay(int kind) { rayKind = kind; }
   __device__ __forceinline__ unsigned long long now() const { return __builtin_amdgcn_s_memtime(); }
   __device__ __forceinline__ void acc(int slot, unsigned long long t0, double &keep) {
     asm volatile("" : "+v"(keep));
     prof[slot] += __builtin_amdgcn_s_memtime() - t0;
   }
 #else
+  __device__ __forceinline__ void markRay(int) {}
   __device__ __forceinline__ unsigned long long now() const { return 0; }
   __device__ __forceinline__ void acc(int, unsigned long long, double &) {}
 #endif
@@ -1457,6 +1480,9 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
 #if PTW_PROFILE_PHASES
   for (int i = 0; i < 12; ++i) ctx.prof[i] = 0;
   for (int i = 0; i < 6; ++i) ctx.mprof[i] = 0;
+  ctx.g00 = ctx.g01 = ctx.g10 = ctx.g11 = ctx.g20 = ctx.g21 = 0;
+  ctx.n00 = ctx.n01 = ctx.n10 = ctx.n11 = ctx.n20 = ctx.n21 = 0;
+  ctx.lastExit = 0, ctx.rayKind = 2, ctx.lastKind = 0, ctx.lastMiss = 0;
   const unsigned long long tStart = __builtin_amdgcn_s_memtime();
 #endif
   for (uint32_t i = 0; i < p.pixCount; ++i) {
@@ -1500,6 +1526,14 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
              "outside intersect()=%.0f\n",
              ctx.mprof[0] / r, ctx.mprof[1] / r, ctx.mprof[2] / r, ctx.mprof[3] / r, ctx.mprof[4] / r,
              ((tEnd - tStart) - ctx.prof[5]) / r);
+    if (WAVES > 1) {
+      const double px = static_cast<double>(p.pixCount);
+      auto avg = [](unsigned long long sum, unsigned long long n) { return n ? static_cast<double>(sum) / n : 0.0; };
+      printf("MASTER cycles from an answer to the next published ray (and answers per sample): primary hit %.0f (%.2f) miss %.0f "
+             "(%.2f) | first ray of a sub-sample hit %.0f (%.2f) miss %.0f (%.2f) | deeper hit %.0f (%.2f) miss %.0f (%.2f)\n",
+             avg(ctx.g00, ctx.n00), ctx.n00 / px, avg(ctx.g01, ctx.n01), ctx.n01 / px, avg(ctx.g10, ctx.n10), ctx.n10 / px,
+             avg(ctx.g11, ctx.n11), ctx.n11 / px, avg(ctx.g20, ctx.n20), ctx.n20 / px, avg(ctx.g21, ctx.n21), ctx.n21 / px);
+    }
   }
 #endif
   ctx.stopWorkers();
@@ -1992,6 +2026,7 @@ struct PixCtxT {
     draw3(u, v, pd);
     return scatter(*this, s, dirIn, u, v, pd, dirOut);
   }
+  __device__ __forceinline__ void markRay(int) {}
   __device__ __forceinline__ unsigned long long now() const { return 0; }
   __device__ __forceinline__ void acc(int, unsigned long long, double &) {}
   __device__ __forceinline__ void draw3(double &a, double &b, double &c) {
