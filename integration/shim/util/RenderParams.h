@@ -1,13 +1,9 @@
-// test stand-in (integration/shim/README.md): the fields of RenderParams hip::Scene reads
+// test stand-in (integration/shim/README.md).  Only what hip::Scene::toPod() reads of the render
+// parameters, as plain members without defaults - the test host fills in every one of them.
 #pragma once
 struct RenderParams {
-  int width{1920};
-  int height{1080};
-  bool preview{false};
-  int samplesPerPixel{40};
-  int maxCpus{1};
-  int maxDepth{5};
-  int firstBounceUSamples{4};
-  int firstBounceVSamples{4};
-  int seed{0};
+  int seed, maxDepth, samplesPerPixel;
+  int firstBounceUSamples, firstBounceVSamples;
+  int width, height;
+  bool preview;
 };

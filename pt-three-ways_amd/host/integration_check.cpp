@@ -63,8 +63,9 @@ int main(int argc, char **argv) {
   const Camera camera(v3(cam.centre), OrthoNormalBasis(n3(cam.axis_x), n3(cam.axis_y), n3(cam.axis_z)),
                       cam.aspect_ratio, cam.camera_plane_dist, cam.reciprocal_height, cam.reciprocal_width,
                       cam.aperture_radius, cam.focal_distance);
-  RenderParams rp;
+  RenderParams rp{};
   rp.width = width, rp.height = height, rp.samplesPerPixel = spp, rp.seed = 1;
+  rp.maxDepth = 5, rp.firstBounceUSamples = 4, rp.firstBounceVSamples = 4, rp.preview = false;
 
   int updates = 0;
   size_t lastTotal = 0;
