@@ -30,7 +30,14 @@ spp; ce 2048x2048 @ 1024 spp as a stated prefix sub-run of the frame) with the s
 the default cfg2 line also carries both, measured once each in the same run, as `other_configs`,
 and the strict-IEEE build's headline number as `strict_fp`.
 
-Prints ONE JSON line on rank 0.
+`python bench.py --gpus N` WITHOUT torch.distributed.run around it launches the N ranks itself
+(re-executes under `python -m torch.distributed.run --nproc-per-node N`): the line always carries
+`n_gpus` = the ranks that rendered and `rccl_ranks` = the size of the library's RCCL communicator.
+PTW_BENCH_SHARE_GPU=1 lets N ranks share fewer GPUs (tests on a one-GPU box: every rank gets its own
+NCCL_HOSTID, which moves RCCL onto its socket transport - same calls, slower wire).
+
+Prints ONE JSON line on rank 0, kept below 6 kB: numbers only - what every field means, how it was
+measured and the standing caveats are in profiles/bench_notes.json (`notes` in the line).
 """
 from __future__ import annotations
 
@@ -106,10 +113,17 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the full-frame comparison with the reference (rmse_vs_ref)")
-    ap.add_argument("--parity-passes", type=int, default=24,
-                    help="passes of the full frame compared with the reference's own code on the host (0: all "
-                         "--spp passes; the default bounds the CPU work - this box's containers get about six "
-                         "cores, on which all 256 passes take 15 minutes)")
+    ap.add_argument("--parity-passes", type=int, default=None,
+                    help="passes of the frame compared with the reference's own code on the host (0: all --spp "
+                         "passes; default 24 for the headline, the bounded windows of SIDE_PARITY for cfg3 / cfg4: "
+                         "this box's containers get about six cores, on which all 256 passes take 15 minutes)")
+    ap.add_argument("--parity-rows", type=int, default=0,
+                    help="rows [0, N) of the frame in that comparison (0: the whole frame / the config's window)")
+    ap.add_argument("--dump-raw", default="",
+                    help="rank 0 saves the last timed step's framebuffer as an ArrayOutput .raw file (tests)")
+    ap.add_argument("--strict-lib", default="libptw_hip_strict.so",
+                    help="the build priced in `strict_fp` (a file name under pt-three-ways_amd/)")
+    ap.add_argument("--strict-parity-passes", type=int, default=4)
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the extra measurement of the other RNG policy")
     ap.add_argument("--accel", choices=["none", "bvh"], default="none",
@@ -159,10 +173,54 @@ def cpu_model():
     return "unknown"
 
 
+def self_launch(args):
+    """`--gpus N` outside torch.distributed.run: start the N ranks ourselves.  (Round 3 degraded to one
+    GPU with a warning here - a SCALE record of N copies of the one-GPU number.)"""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    share = os.environ.get("PTW_BENCH_SHARE_GPU") == "1"
+    if ndev < args.gpus and not share:
+        print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) are visible (PTW_BENCH_SHARE_GPU=1 lets ranks "
+              "share a GPU for testing)", file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def device_of(local_rank, rank):
+    """HIP ordinal of this rank.  One GPU per rank; with PTW_BENCH_SHARE_GPU=1 ranks wrap around the
+    visible GPUs, and every rank poses as its own host towards RCCL (which refuses two ranks of one
+    host on one GPU): socket transport over the loopback interface."""
+    ndev = max(1, torch.cuda.device_count())
+    if os.environ.get("PTW_BENCH_SHARE_GPU") == "1" and int(os.environ.get("WORLD_SIZE", "1")) > ndev:
+        os.environ.setdefault("NCCL_HOSTID", f"ptw-bench-host-{rank}")
+        for k, v in (("NCCL_SOCKET_IFNAME", "lo"), ("NCCL_IB_DISABLE", "1"), ("NCCL_P2P_DISABLE", "1"),
+                     ("NCCL_SHM_DISABLE", "1")):
+            os.environ.setdefault(k, v)
+        return local_rank % ndev
+    return local_rank
+
+
+def agreed_pix_kernel(pkg, ctx, cam, params, rank, use_dist, stream):
+    """PERPIXEL: rank 0 times the policy's two kernels on its shard (ptw_context_calibrate) and every
+    rank runs the winner - two ranks that each measured could disagree, and the gather would wait for
+    the slower kernel."""
+    choice = [ctx.calibrate(cam, params, stream) if rank == 0 else 0]
+    if use_dist and dist.get_world_size() > 1:
+        dist.broadcast_object_list(choice, src=0)
+    return int(choice[0])
+
+
 class Shard:
     """What this rank renders and how the frame is merged afterwards."""
 
-    def __init__(self, pkg, sharding, args, rank, world, local_rank, use_dist):
+    def __init__(self, pkg, sharding, args, rank, world, device, use_dist):
         self.pkg, self.world, self.rank = pkg, world, rank
         self.policy = pkg.RNG_SEQUENTIAL if args.policy == "sequential" else pkg.RNG_PERPIXEL
         extra = {}
@@ -175,26 +233,21 @@ class Shard:
                 self.merge = "gather_rows"
                 self.total_spp = args.spp
                 self.scaling = "strong"
-                self.parallelism = (f"image rows interleaved over {world} GPUs (row y -> rank y % {world}) "
-                                    "+ one RCCL gather of the rows (ptw_comm_gather_rows)")
+                self.parallelism = f"rows y % {world} -> rank, one RCCL gather (tile-sharded)"
             elif args.scaling == "strong":
                 first_pass, spp = sharding.pass_shard(rank, world, args.spp)
                 self.merge = "reduce"
                 self.total_spp = args.spp
                 self.scaling = "strong"
-                self.parallelism = (f"{args.spp} passes split over {world} GPUs + one RCCL reduce(sum) of the "
-                                    "fp64 framebuffer (ptw_comm_reduce_framebuffer).  Under this policy a pass "
-                                    "is ONE serial chain over the frame's pixels (the reference's RNG assignment), "
-                                    "so more GPUs do not shorten a frame of <= 256 passes - they leave CUs idle; "
-                                    "the tile-sharded strong scaling north_star describes is the perpixel_policy "
-                                    "object of this line")
+                self.parallelism = (f"{args.spp} passes over {world} GPUs + one RCCL reduce; seed-matched policy: a pass "
+                                    "is one serial chain, <= 256 passes do NOT strong-scale (scaling_expected); the "
+                                    "tile-sharded number north_star means is value_tile_sharded")
             else:
                 first_pass, spp = sharding.weak_pass_shard(rank, args.spp)
                 self.merge = "reduce"
                 self.total_spp = args.spp * world
                 self.scaling = "weak"
-                self.parallelism = (f"{args.spp} passes per GPU x {world} GPUs (distinct seeds) + one RCCL "
-                                    "reduce(sum) of the fp64 framebuffer (ptw_comm_reduce_framebuffer)")
+                self.parallelism = f"{args.spp} passes per GPU x {world} GPUs (distinct seeds) + one RCCL reduce"
         else:
             self.total_spp = args.spp
             self.scaling = "strong" if args.scaling == "strong" else "weak"
@@ -212,8 +265,8 @@ class Shard:
             self.rows = r1 - r0
         self.params = pkg.default_params(width=args.width, height=args.height, samples_per_pixel=spp,
                                          seed=args.seed, first_pass=first_pass, rng_policy=self.policy,
-                                         device=local_rank, **extra)
-        self.comm = sharding.FrameComm(pkg, local_rank) if self.merge else None
+                                         device=device, **extra)
+        self.comm = sharding.FrameComm(pkg, device) if self.merge else None
 
     def render_and_merge(self, ctx, cam, rgb, cnt, stream):
         if self.params.samples_per_pixel > 0:
@@ -235,6 +288,8 @@ def timed_steps(shard, ctx, cam, bufs, steps, use_dist):
     for i in range(steps):
         rgb, cnt = bufs[-1] if i == steps - 1 else bufs[0]
         shard.render_and_merge(ctx, cam, rgb, cnt, stream)
+    if shard.comm is not None:
+        shard.comm.wait(stream)   # the collectives' completion under the library's watchdog (ptw_comm_wait)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -243,11 +298,11 @@ def timed_steps(shard, ctx, cam, bufs, steps, use_dist):
 
 # ---- CPU legs: the reference's own code on this box's host cores ----------------------------
 def reference_kind(ob, scene_name):
-    """("reference", ...) when oracle/_ref - the reference's own sources compiled where they lie - is on
-    this box, else ("port", ...): the strict C restatement oracle/ptw_oracle.c, which
-    tests/test_oracle_vs_ref.py pins to oracle/_ref bit for bit (radiance and RNG word counts).  A
-    clean checkout has no oracle/_ref (it is git-ignored and only travels with gpurun snapshots); the
-    parity number must not depend on it."""
+    """"reference" when oracle/_ref - the reference's own sources compiled where they lie - is on this
+    box, else "port": the strict C restatement oracle/ptw_oracle.c, which tests/test_oracle_vs_ref.py
+    pins to oracle/_ref bit for bit (radiance and RNG word counts).  A clean checkout has no
+    oracle/_ref (it is git-ignored and only travels with gpurun snapshots); the parity number must
+    not depend on it."""
     if ob.ref_fast is not None and scene_name in ob.SCENE_CAMERAS:
         return "reference"
     return "port"
@@ -277,7 +332,8 @@ def ref_passes(ob, scene_name, view, cam, params, passes, threads, want_words, o
 
 
 def cpu_leg(pkg, ob, scene_name, threads, passes, frame):
-    """One timed CPU leg: `passes` full-frame passes of a frame x frame image on `threads` threads."""
+    """One timed CPU leg: `passes` full-frame passes of a frame x frame image on `threads` threads
+    (what runs and with which flags: profiles/bench_notes.json, `cpu_baseline`)."""
     scene = pkg.Scene()
     cam = scene.build_named(scene_name, frame, frame)
     params = pkg.default_params(width=frame, height=frame, samples_per_pixel=passes, seed=1)
@@ -286,19 +342,8 @@ def cpu_leg(pkg, ob, scene_name, threads, passes, frame):
     t0 = time.perf_counter()
     ref_passes(ob, scene_name, scene.view(), cam, params, list(range(passes)), threads, False)
     dt = time.perf_counter() - t0
-    if kind == "reference":
-        what = ("reference dod::Scene::radiance + Camera::randomRay compiled from /root/reference/src "
-                "with -O2 -march=x86-64-v3 -funsafe-math-optimizations (oracle/_ref), pass loop of "
-                "Scene.cpp:209-219")
-    else:
-        what = "oracle/ptw_oracle.c (C restatement) built with the reference's optimisation flags"
-    return {
-        "value": n / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": kind,
-        "sample": f"{scene_name} {frame}x{frame}, {passes} full-frame passes on {threads} threads "
-                  f"(one pass per thread at a time, as the reference); {what}; "
-                  f"{n} samples in {dt:.1f} s; host: {cpu_model()}, {os.cpu_count()} logical cores visible, "
-                  f"{usable_cpus()} usable",
-    }
+    return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": kind,
+            "sample": f"{scene_name} {frame}x{frame}, {passes} full-frame passes, {n} samples in {dt:.1f} s"}
 
 
 def parity_vs_reference(pkg, ob, ctx, cam, view, scene_name, w, h, total_spp, seed, passes, rows_end, threads):
@@ -346,7 +391,7 @@ def parity_vs_reference(pkg, ob, ctx, cam, view, scene_name, w, h, total_spp, se
         bad = np.argwhere(gw != wd)
         stats["word_mismatch"] += len(bad)
         for y, x in bad[:4]:
-            if len(stats["where"]) < 16:
+            if len(stats["where"]) < 4:
                 stats["where"].append({"pass": int(k), "x": int(x), "y": int(y), "hip_words": int(gw[y, x]),
                                        "ref_words": int(wd[y, x])})
         stats["words_total"] += int(wd.sum(dtype=np.uint64))
@@ -362,8 +407,6 @@ def parity_vs_reference(pkg, ob, ctx, cam, view, scene_name, w, h, total_spp, se
     rmse = np.sqrt(np.mean(diff * diff, axis=(0, 1)))
     identical = np.all(gpu_sum == ref_sum, axis=2)
     nsamp = int(w) * rows_end * spp
-    where = (f"every pixel of the {w}x{h} frame" if rows_end == h else
-             f"rows [0, {rows_end}) of the {w}x{h} frame (a prefix: what the full render produces for them)")
     return {
         "rmse_vs_ref": [float(x) for x in rmse],
         "max_abs_diff": float(np.max(np.abs(diff))),
@@ -371,28 +414,19 @@ def parity_vs_reference(pkg, ob, ctx, cam, view, scene_name, w, h, total_spp, se
         "samples_word_count_differs": stats["word_mismatch"], "samples": nsamp,
         "word_count_differences": stats["where"],
         "counts_equal": bool(np.all(gpu_cnt == spp)),
-        "parity_passes": spp, "parity_kernel": parity_kernel,
-        "parity_note": f"{where}, passes [0, {spp}) of the {total_spp} (seeds {seed}..{seed + spp - 1}); all 256 "
-                       "passes of the headline frame: profiles/ (the round's *_full_parity.json)",
+        "parity_passes": spp, "parity_rows": [0, rows_end], "parity_kernel": parity_kernel,
         "mean_words_per_sample": stats["words_total"] / float(nsamp),
         "reference_kind": kind,
-        "reference": ("oracle/_ref: the reference's own src/dod/Scene.cpp + src/math + ArrayOutput compiled "
-                      "where they lie (-O2 -march=x86-64-v3 -funsafe-math-optimizations), pass loop of "
-                      "Scene.cpp:209-219, passes added in pass order") if kind == "reference" else
-                     ("oracle/ptw_oracle.c, the C restatement (oracle/_ref is not on this box); "
-                      "tests/test_oracle_vs_ref.py pins it to the compiled reference bit for bit"),
-        "compared": "per-pixel means (sum / count, linear fp64); fp64 sums bitwise; RNG words consumed by "
-                    "every (pass, pixel) sample",
     }, {
         "value": nsamp / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": kind,
-        "sample": f"{scene_name} {w}x{h}, rows [0, {rows_end}), {spp} passes on {threads} threads (the parity "
-                  f"reference of this run); {nsamp} samples in {dt:.1f} s; host: {cpu_model()}, {os.cpu_count()} "
-                  f"logical cores visible, {usable_cpus()} usable (affinity / cgroup quota)",
+        "sample": f"the parity reference of this run: {scene_name} {w}x{h} rows [0, {rows_end}) x {spp} passes, "
+                  f"{nsamp} samples in {dt:.1f} s",
     }
 
 
 # Bounded parity windows of the side configurations (rows of the frame x passes): about 10-25 s of
-# host work each on six cores.
+# host work each on six cores.  `--parity-rows` / `--parity-passes` widen them (`--config cfg3
+# --parity-rows 1024 --parity-passes 2`: one whole-frame comparison, kept under profiles/).
 SIDE_PARITY = {"cfg3": dict(rows_end=64, passes=6), "cfg4": dict(rows_end=4, passes=6)}
 
 
@@ -445,74 +479,73 @@ def side_config(pkg, ob, name, device, threads, want_parity):
     dt = time.perf_counter() - t0
     stats = ctx.stats(reset=True)
     ctx.enable_stats(False)
+    roof = roofline_of(stats, view.num_triangles, view.num_spheres)
     out = {
-        "config": name, "metric": metric_name(cfg["scene"], w, h, spp),
-        "value": w * rows * spp / dt / 1e6, "unit": "Msamples/s", "n_gpus": 1, "steps": 1, "warmup": 0,
-        "ms_per_step": dt * 1e3, "dtype": "f64",
-        "workload": f"{cfg['scene']} {w}x{h} @ {spp} spp, maxDepth 5, 4x4 first bounce, rng_policy=sequential"
-                    + (f"; TIMED SUB-RUN: image rows [{cfg['rows'].replace(':', ', ')}) of the {w}x{h} frame "
-                       f"({rows}/{h} of its samples; the whole frame would take {dt * h / rows / 60:.0f} min)"
+        "config": name, "value": w * rows * spp / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3,
+        "workload": f"{cfg['scene']} {w}x{h} @ {spp} spp, sequential"
+                    + (f"; SUB-RUN rows [{cfg['rows'].replace(':', ', ')}) = {rows}/{h} of the frame"
                        if cfg["rows"] else ""),
-        "triangles": view.num_triangles, "spheres": view.num_spheres,
         "frame_rows_complete": bool((cnt[:rows] == spp).all().item()),
-        "roofline": roofline_of(stats, view.num_triangles, view.num_spheres),
+        "kernel": roof["kernel"], "frac": roof["frac"], "achieved_tflops": roof["achieved"],
+        "avg_launch_ms": roof["avg_launch_ms"], "launches": roof["launches"], "rays_per_sample": roof["rays_per_sample"],
     }
     if want_parity:
         par, leg = parity_vs_reference(pkg, ob, ctx, cam, view, cfg["scene"], w, h, spp, 1,
                                        SIDE_PARITY[name]["passes"], SIDE_PARITY[name]["rows_end"], threads)
-        out.update(par)
-        out["cpu_leg"] = leg
+        for k in ("rmse_vs_ref", "samples_word_count_differs", "samples", "parity_kernel", "parity_rows",
+                  "parity_passes", "pixels_bit_identical", "pixels"):
+            out[k] = par[k]
     del rgb, cnt
     return out
 
 
 def strict_leg(args):
-    """The headline frame under the strict-IEEE build (libptw_hip_strict.so: no FMA contraction, IEEE
-    division and square root - the build whose every decision matches the reference's),
+    """The headline frame under the build whose every decision matches the reference's,
     measured by this script in a child process so that the index-exact configuration has a measured
-    price next to the shipped one."""
+    price next to the shipped one.  `--strict-lib` picks the build: libptw_hip_strict.so
+    (-ffp-contract=off) by default."""
     import subprocess
-    lib = ROOT / "pt-three-ways_amd" / "libptw_hip_strict.so"
+    lib = ROOT / "pt-three-ways_amd" / args.strict_lib
     if not lib.exists():
-        return {"value": None, "note": "libptw_hip_strict.so is not built (make -C pt-three-ways_amd strict)"}
+        return {"value": None, "note": f"{args.strict_lib} is not built (make -C pt-three-ways_amd strict)"}
     cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "1", "--warmup", "0", "--no-secondary",
-           "--no-cpu-baseline", "--no-other-configs", "--no-strict", "--parity-passes", "4"]
+           "--no-cpu-baseline", "--no-other-configs", "--no-strict", "--parity-passes", str(args.strict_parity_passes)]
     try:
         proc = subprocess.run(cmd, env=dict(os.environ, PTW_LIB_PATH=str(lib)), capture_output=True, text=True,
-                              timeout=600)
+                              timeout=1500)
         line = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1]
         r = json.loads(line)
     except Exception as e:  # noqa: BLE001
         return {"value": None, "note": f"strict leg failed: {e!r}"}
     return {
-        "value": r["value"], "unit": "Msamples/s", "ms_per_step": r["ms_per_step"], "steps": 1,
+        "value": r["value"], "unit": "Msamples/s", "ms_per_step": r["ms_per_step"],
         "flips": r.get("samples_word_count_differs"), "parity_passes": r.get("parity_passes"),
         "rmse_vs_ref": r.get("rmse_vs_ref"), "pixels_bit_identical": r.get("pixels_bit_identical"),
-        "kernel": r["roofline"]["kernel"], "frac": r["roofline"]["frac"],
-        "build": "libptw_hip_strict.so: -ffp-contract=off -DPTW_FAST_MATH=0 (IEEE division and square root)",
-        "note": "same workload as `value`, one timed step in a child process of this run; `flips` = samples whose "
-                "RNG word count differs from the reference's over `parity_passes` whole-frame passes",
+        "kernel": r["roofline"]["kernel"], "frac": r["roofline"]["frac"], "build": args.strict_lib,
     }
 
 
 def main():
     args = parse_args()
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not use_dist:
+        self_launch(args)          # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = device_of(local_rank, rank)
     # launched by torch.distributed.run (even with one rank): one process per GPU
-    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world:
+        torch.cuda.set_device(device)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+    if args.gpus != world:   # launched by someone else's torchrun with another rank count: say what ran
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torchrun",
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the line reports n_gpus={world}",
                   file=sys.stderr)
         args.gpus = world
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(device)
 
     pkg = entry.load_package()
     import importlib
@@ -522,13 +555,14 @@ def main():
     cam = scene.build_named(args.scene, w, h)
     view = scene.view()
     ntri, nsph = view.num_triangles, view.num_spheres
-    ctx = pkg.Context(local_rank)
+    ctx = pkg.Context(device)
     t0 = time.perf_counter()
     ctx.set_scene(scene)
     scene_upload_ms = (time.perf_counter() - t0) * 1e3
 
-    shard = Shard(pkg, sharding, args, rank, world, local_rank, use_dist)
+    shard = Shard(pkg, sharding, args, rank, world, device, use_dist)
     policy = shard.policy
+    stream = torch.cuda.current_stream().cuda_stream
     scratch = (torch.zeros((h, w, 3), dtype=torch.float64, device="cuda"),
                torch.zeros((h, w), dtype=torch.int32, device="cuda"))
     final = (torch.zeros_like(scratch[0]), torch.zeros_like(scratch[1]))
@@ -536,9 +570,10 @@ def main():
     # untimed: load code objects / allocate staging with a tiny render, then the W warm-up steps
     tiny = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=args.seed,
                               rng_policy=pkg.RNG_PERPIXEL, row_begin=0, row_end=1)
-    ctx.render(cam, tiny, scratch[0].data_ptr(), scratch[1].data_ptr(), 0,
-               torch.cuda.current_stream().cuda_stream)
+    ctx.render(cam, tiny, scratch[0].data_ptr(), scratch[1].data_ptr(), 0, stream)
     torch.cuda.synchronize()
+    if policy == pkg.RNG_PERPIXEL and args.accel == "none":   # one kernel for every rank, chosen once, untimed
+        shard.params.pix_kernel = agreed_pix_kernel(pkg, ctx, cam, shard.params, rank, use_dist, stream)
     if args.warmup > 0:
         timed_steps(shard, ctx, cam, [scratch], args.warmup, use_dist)
     scratch[0].zero_()
@@ -554,6 +589,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if args.dump_raw and rank == 0:
+        pkg.raw_save(args.dump_raw, final[0].cpu().numpy(), final[1].cpu().numpy().astype(np.uint32))
     samples_per_step = w * shard.rows * shard.total_spp
     total_samples = samples_per_step * args.steps
     value = total_samples / elapsed / 1e6
@@ -570,16 +607,14 @@ def main():
         hbm_gbs = samples_per_launch * HBM_BYTES_PER_SAMPLE_TRACE / avg_launch_s / 1e9
         kernel_variant = stats.trace_kernel.decode() or "unknown"   # reported by the library
         kernel = "traceSequential" if policy == pkg.RNG_SEQUENTIAL else "tracePerPixel"
-        traffic, traffic_source = None, None
+        traffic = None
         traffic_file = ROOT / "profiles" / "hbm_traffic.json"
-        if traffic_file.exists():
+        if traffic_file.exists():   # rocprofv3 --pmc passes of an earlier run, scaled to this run's samples per launch
             try:
                 table = json.loads(traffic_file.read_text())
                 rec = table.get(f"{kernel_variant}:{args.scene}") or table.get(f"{kernel}:{args.scene}")
                 if rec:
                     traffic = rec["hbm_bytes_per_sample"] * samples_per_launch
-                    traffic_source = ("profiles/hbm_traffic.json (rocprofv3 --pmc passes of an earlier run: "
-                                      f"{rec.get('measured_on', 'see file')}), scaled to this run's samples per launch")
             except Exception:
                 traffic = None
         fb_bytes = w * h * 28
@@ -596,8 +631,9 @@ def main():
         d2h_ms = (time.perf_counter() - t0) * 1e3
         result = {
             "metric": metric_name(args.scene, w, h, shard.total_spp),
-            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "value": value, "unit": "Msamples/s", "n_gpus": world,
+            "rccl_ranks": shard.comm.world if shard.comm is not None else 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": shard.scaling, "vs_baseline": None, "dtype": "f64",
             "data": f"bundled scene ({args.scene}: the reference's .obj + the primitives src/main/main.cpp adds), seed 1",
             "config": {
@@ -611,48 +647,39 @@ def main():
                 "accel": args.accel,
             },
             "end_to_end_ms_per_step": elapsed / args.steps * 1e3 + scene_upload_ms + h2d_ms + d2h_ms,
-            "end_to_end_note": f"ms_per_step + scene upload incl. per-primitive precompute ({scene_upload_ms:.1f} ms) "
-                               f"+ framebuffer H2D ({h2d_ms:.2f} ms) + D2H ({d2h_ms:.2f} ms, 28 B/pixel each "
-                               "way over PCIe), each measured once in this run; never part of `value`",
+            "scene_upload_ms": scene_upload_ms, "h2d_ms": h2d_ms, "d2h_ms": d2h_ms,
             "roofline": {
                 "bound": "valu_fp64", "kernel": kernel_variant,
                 "achieved": achieved_tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tflops / FP64_VALU_PEAK_TFLOPS,
-                "traffic": traffic, "traffic_source": traffic_source,
+                "traffic": traffic,
                 "avg_launch_ms": avg_launch_s * 1e3, "launches": int(stats.trace_launches),
                 "algorithmic_flop_per_launch": rays_per_launch * flop_per_ray,
                 "rays_per_sample": stats.rays / max(1, stats.samples),
-                "note": "branchy scalar fp64, no MFMA: the binding roof is the fp64 vector ALU "
-                        "(SURVEY.md 8d). algorithmic flop = intersect() calls x (ntri*45 + nsph*19)"
-                        + ("; ACCELERATED MODE: `achieved` prices every ray at the brute-force test count the "
-                           "reference would do - an EFFECTIVE rate, not arithmetic performed (the BVH skips most "
-                           "tests); separate from and not comparable with the headline" if args.accel != "none" else ""),
             },
             "roofline_hbm": {
                 "bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": hbm_gbs / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": samples_per_launch * HBM_BYTES_PER_SAMPLE_TRACE,
-                "note": "compulsory HBM traffic of this path is 24 B of staged radiance per sample; "
-                        "<<1 % of peak by construction",
             },
             "resolve_kernel_ms_total": stats.resolve_ms,
+            "notes": "profiles/bench_notes.json",
         }
 
     # -- the other RNG policy, same workload, same run: at N > 1 it is the tile-sharded form
     #    north_star words (image rows interleaved over the GPUs + one RCCL gather) ---------------
     if not args.no_secondary and policy == pkg.RNG_SEQUENTIAL and not args.rows:
+        rows_kw = sharding.interleaved_rows(rank, world) if world > 1 else {}
         p2 = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=args.seed,
-                                rng_policy=pkg.RNG_PERPIXEL, device=local_rank,
-                                **(sharding.interleaved_rows(rank, world) if world > 1 else {}))
+                                rng_policy=pkg.RNG_PERPIXEL, device=device, **rows_kw)
         rgb2 = torch.zeros_like(final[0])
         cnt2 = torch.zeros_like(final[1])
-        stream = torch.cuda.current_stream().cuda_stream
-        # untimed warm-up (the analogue of the W warm-up steps): the library picks this policy's kernel
-        # with a timed trial at the first large render of a scene + frame shape
+        # untimed (the analogue of the W warm-up steps): rank 0 times the policy's two kernels on its
+        # shard, every rank runs the winner; then a short render of it loads the code objects
+        p2.pix_kernel = agreed_pix_kernel(pkg, ctx, cam, p2, rank, use_dist, stream)
         warm = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=args.seed, rng_policy=pkg.RNG_PERPIXEL,
-                                  device=local_rank, row_begin=0,
-                                  row_end=max(1, min(h, ((17 << 20) * world) // (w * spp) + world)),
-                                  **(sharding.interleaved_rows(rank, world) if world > 1 else {}))
+                                  device=device, row_begin=0, row_end=min(h, 2 * world), pix_kernel=p2.pix_kernel,
+                                  **rows_kw)
         ctx.render(cam, warm, scratch[0].data_ptr(), scratch[1].data_ptr(), 0, stream)
         torch.cuda.synchronize()
         ctx.enable_stats(True)
@@ -664,6 +691,7 @@ def main():
         ctx.render(cam, p2, rgb2.data_ptr(), cnt2.data_ptr(), 0, stream)
         if shard.comm is not None:
             shard.comm.gather_rows(rgb2, cnt2, dst=0, stream=stream)
+            shard.comm.wait(stream)
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -680,38 +708,31 @@ def main():
             result["perpixel_policy"] = {
                 "value": w * h * spp / dt2 / 1e6, "unit": "Msamples/s", "ms_per_step": dt2 * 1e3, "n_gpus": world,
                 "scaling": "strong",
-                "parallelism": "single GPU" if world == 1 else
-                               f"image rows interleaved over {world} GPUs + one RCCL gather of the rows "
-                               "(ptw_comm_gather_rows); all counts on rank 0 checked",
+                "parallelism": "single GPU" if world == 1 else f"rows y % {world} -> rank, one RCCL gather",
                 "frame_complete_on_root": bool((cnt2 == spp).all().item()),
-                "roofline": {"bound": "valu_fp64", "kernel": s2.trace_kernel.decode(), "achieved": tf,
-                             "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": tf / FP64_VALU_PEAK_TFLOPS, "rank": 0,
-                             "avg_launch_ms": s2.trace_ms / max(1, s2.trace_launches)},
-                "note": "same estimator and workload, independent sfc32 stream per (pass, pixel); "
-                        "not seed-matched with the reference; exact vs the oracle under the same policy",
+                "kernel": s2.trace_kernel.decode(), "achieved_tflops_rank0": tf, "frac_rank0": tf / FP64_VALU_PEAK_TFLOPS,
+                "avg_launch_ms": s2.trace_ms / max(1, s2.trace_launches),
                 "mean_abs_diff_vs_sequential_image":
                     float((rgb2 / spp - final[0] / max(1, shard.total_spp)).abs().mean().item()),
             }
+            if world > 1:   # what north_star's ">= 6x at 8 GPUs via image tiling" is a statement about
+                result["value_tile_sharded"] = result["perpixel_policy"]["value"]
         del rgb2, cnt2
+    elif rank == 0 and world > 1 and policy == pkg.RNG_PERPIXEL:
+        result["value_tile_sharded"] = value
 
     if rank == 0 and world > 1:
         # Machine-readable expectation for a reader of the scaling curve (the driver computes the
         # efficiency itself): under the sequential policy a pass is ONE serial chain over the frame's
         # pixels, so splitting <= 256 passes over more GPUs does not shorten the frame.
-        cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        cus = torch.cuda.get_device_properties(device).multi_processor_count
         per_rank = -(-args.spp // world) if shard.scaling == "strong" else args.spp
         seq_expected = 1.0 if (shard.scaling == "strong" and args.spp <= cus) else \
             (float(world) if shard.scaling == "weak" else min(float(world), max(1.0, args.spp / cus)))
         result["scaling_expected"] = {
             "value_policy": args.policy,
-            "sequential": {
-                "expected_speedup_vs_1gpu": seq_expected, "passes_per_gpu": per_rank, "cus_per_gpu": cus,
-                "why": "seed-matched policy: one mt19937 stream per pass consumed pixel after pixel (Scene.cpp:211-217) - "
-                       "the time of a frame is the time of ONE pass's chain while passes <= CUs; passes are the only "
-                       "thing the reference's RNG assignment leaves to shard (DESIGN.md 7)"},
-            "perpixel": {"expected_speedup_vs_1gpu": 0.9 * world,
-                         "why": "independent stream per (pass, pixel): interleaved rows + one gather; see perpixel_policy"},
+            "sequential": {"expected_speedup_vs_1gpu": seq_expected, "passes_per_gpu": per_rank, "cus_per_gpu": cus},
+            "perpixel": {"expected_speedup_vs_1gpu": 0.9 * world},
         }
     if rank == 0 and world == 1 and (not args.no_cpu_baseline or not args.no_parity):
         sys.path.insert(0, str(ROOT / "tests"))
@@ -721,10 +742,13 @@ def main():
             rows_end = h
             if args.rows:
                 rows_end = int(args.rows.split(":")[1])
-            if args.config in SIDE_PARITY:   # the large scenes: a bounded window (SIDE_PARITY)
-                rows_end, passes = SIDE_PARITY[args.config]["rows_end"], SIDE_PARITY[args.config]["passes"]
-            else:
-                passes = args.parity_passes
+            passes = args.parity_passes
+            if args.config in SIDE_PARITY:   # the large scenes: a bounded window (SIDE_PARITY) unless asked
+                rows_end = SIDE_PARITY[args.config]["rows_end"]
+                passes = SIDE_PARITY[args.config]["passes"] if passes is None else passes
+            if args.parity_rows > 0:
+                rows_end = min(h, args.parity_rows)
+            passes = 24 if passes is None else passes
             parity, all_cores_leg = parity_vs_reference(pkg, ob, ctx, cam, view, args.scene, w, h, spp, args.seed,
                                                         passes, rows_end, usable_cpus())
             result.update(parity)
@@ -736,6 +760,7 @@ def main():
             result["cpu_baseline"] = six       # the comparator north_star names: 6 threads
             legs = [one, six] + legs
         result["cpu_baseline_legs"] = legs
+        result["host"] = {"cpu": cpu_model(), "logical_cores": os.cpu_count(), "usable_cores": usable_cpus()}
         if args.is_default_workload and policy == pkg.RNG_SEQUENTIAL:
             del scratch, final
             torch.cuda.empty_cache()
@@ -746,15 +771,17 @@ def main():
                 return time.perf_counter() - PROCESS_T0 < SIDE_LEG_DEADLINE_S
             if not args.no_other_configs:   # BASELINE cfg3 / cfg4, once each, same run
                 result["other_configs"] = [
-                    side_config(pkg, ob, name, local_rank, usable_cpus(), not args.no_parity) if in_time() else
-                    {"config": name, "value": None, "note": f"skipped: {SIDE_LEG_DEADLINE_S} s of process time were used up; "
-                                                            f"run `python bench.py --config {name}`"}
+                    side_config(pkg, ob, name, device, usable_cpus(), not args.no_parity) if in_time() else
+                    {"config": name, "value": None, "note": f"skipped after {SIDE_LEG_DEADLINE_S} s; run --config {name}"}
                     for name in ("cfg3", "cfg4")]
             if not args.no_strict:
                 result["strict_fp"] = strict_leg(args) if in_time() else \
-                    {"value": None, "note": f"skipped: {SIDE_LEG_DEADLINE_S} s of process time were used up"}
+                    {"value": None, "note": f"skipped after {SIDE_LEG_DEADLINE_S} s"}
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        line = json.dumps(result)
+        if len(line) > 6000:   # the driver's record keeps 8 kB + 2 kB of the line: stay whole
+            print(f"bench.py: the line is {len(line)} bytes (> 6000)", file=sys.stderr)
+        print(line, flush=True)
     if shard.comm:
         shard.comm.close()
     if use_dist:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PTW_ABI_VERSION 3
+#define PTW_ABI_VERSION 4
 
 typedef enum ptw_status {
   PTW_OK = 0,
@@ -59,6 +59,18 @@ typedef enum ptw_rng_policy { PTW_RNG_SEQUENTIAL = 0, PTW_RNG_PERPIXEL = 1 } ptw
  *         every sample is bit-identical to the NONE result while the work (tests per ray) is not
  *         the reference's.  PTW_RNG_PERPIXEL only. */
 typedef enum ptw_accel { PTW_ACCEL_NONE = 0, PTW_ACCEL_BVH = 1 } ptw_accel;
+
+/* Which of the PTW_RNG_PERPIXEL policy's two radiance kernels runs (same samples, same bytes;
+ * which one is faster depends on how uniformly long the scene's paths are, which no host-side
+ * number says - closed scenes favour LOCKSTEP, open ones PERSISTENT):
+ *  AUTO        the kernel ptw_context_calibrate() last measured faster for this scene, camera and
+ *              frame shape on the context; PERSISTENT when nothing was calibrated;
+ *  LOCKSTEP    a lane traces whole samples, the lanes of a wave run each level's shading together;
+ *  PERSISTENT  a lane whose path ends takes the next sample from a device-wide queue.
+ * Ignored under PTW_RNG_SEQUENTIAL and in the accelerated mode. */
+typedef enum ptw_pix_kernel {
+  PTW_PIX_KERNEL_AUTO = 0, PTW_PIX_KERNEL_LOCKSTEP = 1, PTW_PIX_KERNEL_PERSISTENT = 2
+} ptw_pix_kernel;
 
 /* MaterialSpec, src/util/MaterialSpec.h:7-12 (same field order, 72 bytes). */
 typedef struct ptw_material {
@@ -123,6 +135,7 @@ typedef struct ptw_render_params {
   int32_t row_stride;
   int32_t row_phase;
   int32_t accel;                 /* ptw_accel; default PTW_ACCEL_NONE                       */
+  int32_t pix_kernel;            /* ptw_pix_kernel; default PTW_PIX_KERNEL_AUTO             */
 } ptw_render_params;
 
 /* Progress callback, the analogue of `updateFunc(output)` (src/dod/Scene.cpp:245) and of
@@ -239,17 +252,26 @@ int ptw_context_set_scene(ptw_context *ctx, const ptw_scene_view *scene);
 /* Enqueue the render on `hip_stream` (a hipStream_t, NULL = default stream).  d_rgb_sum and
  * d_counts are DEVICE pointers to width*height*3 doubles / width*height uint32 and are
  * accumulated into.  Asynchronous: nothing here waits for the device; the caller synchronises
- * the stream.  (One exception: the first PTW_RNG_PERPIXEL render of 16 M samples or more after
- * ptw_context_set_scene times a trial of the policy's two kernels - about two million samples each -
- * to pick the faster one for this scene and frame shape, and waits for that trial.)  A context owns one set of scratch buffers (generator states, staging): renders
+ * the stream.  A context owns one set of scratch buffers (generator states, staging): renders
  * of one context must be enqueued on the SAME stream (they then run one after another in stream
  * order); to change streams, or before ptw_context_set_scene, synchronise the stream of the
- * previous render.  Renders on different contexts are independent.  If d_words is not NULL it receives, per pass and pixel
- * ([pass][y][x], uint32), the number of 32-bit RNG words that sample consumed (parity
- * instrumentation; SEQUENTIAL and PERPIXEL). */
+ * previous render.  Renders on different contexts are independent.  If d_words is not NULL it
+ * receives, per pass and pixel ([pass][y][x], uint32), the number of 32-bit RNG words that sample
+ * consumed (parity instrumentation; SEQUENTIAL and PERPIXEL). */
 int ptw_context_render(ptw_context *ctx, const ptw_camera *camera,
                        const ptw_render_params *params, void *d_rgb_sum, void *d_counts,
                        void *d_words, void *hip_stream);
+/* PTW_RNG_PERPIXEL: times a trial of the policy's two kernels (about two million samples each,
+ * image rows spread over the frame `params` describes, outputs into the context's staging buffer
+ * only) on `hip_stream`, WAITS for it (10-30 ms), remembers the faster one on the context for this
+ * scene + camera + frame shape - what PTW_PIX_KERNEL_AUTO then resolves to - and returns it in
+ * *kernel_out (a ptw_pix_kernel; may be NULL).  Multi-GPU hosts calibrate on ONE rank and hand the
+ * answer to the others in ptw_render_params.pix_kernel, so that every shard of a frame runs the
+ * same kernel.  ptw_render / ptw_render_ex (synchronous calls) do this themselves for renders of
+ * 16 M samples or more.  Under PTW_RNG_SEQUENTIAL / the accelerated mode: PTW_PIX_KERNEL_AUTO, no
+ * trial. */
+int ptw_context_calibrate(ptw_context *ctx, const ptw_camera *camera,
+                          const ptw_render_params *params, void *hip_stream, int32_t *kernel_out);
 /* Per-kernel timing gathered with hipEvents on the launch stream when enabled. */
 typedef struct ptw_kernel_stats {
   uint64_t trace_launches;   /* launches of the radiance kernel since the last reset   */
@@ -298,6 +320,13 @@ int ptw_comm_create_loopback(int32_t world_size, int32_t device, ptw_comm **out_
  * rendezvous - after which the only valid call is ptw_comm_destroy. */
 int ptw_comm_abort(ptw_comm *comm);
 void ptw_comm_destroy(ptw_comm *comm);
+/* Waits until everything enqueued on `hip_stream` - the collectives above included - has finished,
+ * WATCHING the communicator while it waits: an asynchronous RCCL error (ncclCommGetAsyncError: a
+ * peer died, a link failed) or `timeout_ms` without completion (0: PTW_COLLECTIVE_TIMEOUT_S from the
+ * environment, default 300 s) aborts the communicator - which ends its kernels on the device - and
+ * returns PTW_ERR_HIP.  The collectives are asynchronous and a peer that disappears after the
+ * enqueue would otherwise leave hipStreamSynchronize waiting forever. */
+int ptw_comm_wait(ptw_comm *comm, void *hip_stream, int32_t timeout_ms);
 /* `output += pass` for whole framebuffers (ArrayOutput::operator+=, ArrayOutput.cpp:48-56):
  * the fp64 sums (npix * 3) and the u32 counts (npix) of every rank are summed into rank `root`'s
  * buffers (ncclReduce; the other ranks' buffers are left as they are).  In place. */

@@ -27,6 +27,9 @@ RNG_SEQUENTIAL = 0
 RNG_PERPIXEL = 1
 ACCEL_NONE = 0
 ACCEL_BVH = 1
+PIX_KERNEL_AUTO = 0
+PIX_KERNEL_LOCKSTEP = 1
+PIX_KERNEL_PERSISTENT = 2
 
 STATUS_NAMES = {
     0: "PTW_OK", 1: "PTW_ERR_INVALID", 2: "PTW_ERR_NO_DEVICE", 3: "PTW_ERR_HIP", 4: "PTW_ERR_IO",
@@ -99,7 +102,8 @@ class RenderParams(C.Structure):
                 ("first_bounce_u", C.c_int32), ("first_bounce_v", C.c_int32),
                 ("seed", C.c_int32), ("first_pass", C.c_int32), ("rng_policy", C.c_int32),
                 ("row_begin", C.c_int32), ("row_end", C.c_int32), ("device", C.c_int32),
-                ("row_stride", C.c_int32), ("row_phase", C.c_int32), ("accel", C.c_int32)]
+                ("row_stride", C.c_int32), ("row_phase", C.c_int32), ("accel", C.c_int32),
+                ("pix_kernel", C.c_int32)]
 
 
 class KernelStats(C.Structure):
@@ -163,6 +167,7 @@ _sig("ptw_comm_create_all", C.c_int, C.c_int32, C.POINTER(C.c_int32), C.POINTER(
 _sig("ptw_comm_create_loopback", C.c_int, C.c_int32, C.c_int32, C.POINTER(C.c_void_p))
 _sig("ptw_comm_abort", C.c_int, C.c_void_p)
 _sig("ptw_comm_destroy", None, C.c_void_p)
+_sig("ptw_comm_wait", C.c_int, C.c_void_p, C.c_void_p, C.c_int32)
 _sig("ptw_comm_reduce_framebuffer", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
      C.c_int32, C.c_void_p)
 _sig("ptw_comm_gather_rows", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
@@ -172,6 +177,8 @@ _sig("ptw_context_destroy", None, C.c_void_p)
 _sig("ptw_context_set_scene", C.c_int, C.c_void_p, C.POINTER(SceneView))
 _sig("ptw_context_render", C.c_int, C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams),
      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+_sig("ptw_context_calibrate", C.c_int, C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p,
+     C.POINTER(C.c_int32))
 _sig("ptw_context_enable_stats", C.c_int, C.c_void_p, C.c_int32)
 _sig("ptw_context_get_stats", C.c_int, C.c_void_p, C.POINTER(KernelStats), C.c_int32)
 _sig("ptw_context_intersect", C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
@@ -373,6 +380,11 @@ class Comm:
             lib.ptw_comm_destroy(self._h)
             self._h = C.c_void_p()
 
+    def wait(self, stream: int = 0, timeout_ms: int = 0):
+        """Completion of everything enqueued on `stream` under the watchdog (ptw_comm_wait): an
+        asynchronous RCCL error or the timeout aborts the communicator and raises PtwError."""
+        _check(lib.ptw_comm_wait(self._h, C.c_void_p(stream) if stream else None, int(timeout_ms)))
+
     def reduce_framebuffer(self, d_rgb_sum: int, d_counts: int, npix: int, root: int = 0, stream: int = 0):
         _check(lib.ptw_comm_reduce_framebuffer(self._h, C.c_void_p(d_rgb_sum), C.c_void_p(d_counts),
                                                npix, root, C.c_void_p(stream) if stream else None))
@@ -412,6 +424,14 @@ class Context:
                                       C.c_void_p(d_rgb_sum), C.c_void_p(d_counts),
                                       C.c_void_p(d_words) if d_words else None,
                                       C.c_void_p(stream) if stream else None))
+
+    def calibrate(self, camera: Camera, params: RenderParams, stream: int = 0) -> int:
+        """PERPIXEL: times the policy's two kernels on this scene + frame shape (blocks), remembers
+        and returns the faster one (PIX_KERNEL_LOCKSTEP / PIX_KERNEL_PERSISTENT)."""
+        out = C.c_int32(0)
+        _check(lib.ptw_context_calibrate(self._h, C.byref(camera), C.byref(params),
+                                         C.c_void_p(stream) if stream else None, C.byref(out)))
+        return int(out.value)
 
     def enable_stats(self, enable=True):
         _check(lib.ptw_context_enable_stats(self._h, int(bool(enable))))

@@ -28,11 +28,14 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace ptw {
@@ -45,6 +48,7 @@ struct Rccl {
   decltype(&ncclCommInitAll) commInitAll = nullptr;
   decltype(&ncclCommDestroy) commDestroy = nullptr;
   decltype(&ncclCommAbort) commAbort = nullptr;
+  decltype(&ncclCommGetAsyncError) commGetAsyncError = nullptr;
   decltype(&ncclGetErrorString) getErrorString = nullptr;
   decltype(&ncclReduce) reduce = nullptr;
   decltype(&ncclSend) send = nullptr;
@@ -75,6 +79,7 @@ const Rccl &rccl() {
     sym(api.commInitAll, "ncclCommInitAll");
     sym(api.commDestroy, "ncclCommDestroy");
     sym(api.commAbort, "ncclCommAbort");
+    sym(api.commGetAsyncError, "ncclCommGetAsyncError");
     sym(api.getErrorString, "ncclGetErrorString");
     sym(api.reduce, "ncclReduce");
     sym(api.send, "ncclSend");
@@ -97,6 +102,18 @@ void checkHip(hipError_t e, const char *what) {
 
 static_assert(PTW_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
 
+// How long a rank waits for its peers before it gives up on the communicator (ptw_comm_wait with
+// timeout 0, and the host rendezvous of the loopback transport): PTW_COLLECTIVE_TIMEOUT_S, default
+// 300 s - far above any framebuffer collective (462 MB over xGMI: milliseconds), far below forever.
+std::chrono::milliseconds collectiveTimeout(int32_t timeoutMs = 0) {
+  if (timeoutMs > 0) return std::chrono::milliseconds(timeoutMs);
+  if (const char *v = std::getenv("PTW_COLLECTIVE_TIMEOUT_S")) {
+    const double s = std::atof(v);
+    if (s > 0) return std::chrono::milliseconds(static_cast<long long>(s * 1e3));
+  }
+  return std::chrono::milliseconds(300000);
+}
+
 // ---- loopback transport ---------------------------------------------------------------------
 // A message is a device buffer plus the event after which its contents are final on the sender's
 // stream.  The receiver makes its own stream wait for that event, consumes the buffer (copy or
@@ -106,8 +123,8 @@ static_assert(PTW_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
 struct LoopMessage {
   const void *ptr = nullptr;
   size_t bytes = 0;
-  hipEvent_t ready = nullptr;    // owned by the sender
-  hipEvent_t consumed = nullptr; // owned by the receiver
+  hipEvent_t ready = nullptr;    // owned by the sender (one per peer and channel, re-recorded per message)
+  hipEvent_t consumed = nullptr; // owned by the receiver (likewise)
   int state = 0;                 // 0 empty, 1 posted, 2 consumed
 };
 
@@ -125,6 +142,20 @@ struct LoopbackHub {
     std::lock_guard<std::mutex> lock(m);
     aborted = true;
     cv.notify_all();
+  }
+  // Waits (lock held) until `ready()` or the communicator is given up; a peer that never arrives is
+  // an error after collectiveTimeout(), not a hang - and the error aborts the hub, so that whoever
+  // waits for THIS rank is released too.
+  template <typename Ready>
+  void await(std::unique_lock<std::mutex> &lock, const char *what, Ready &&ready) {
+    const bool ok = cv.wait_for(lock, collectiveTimeout(), [&] { return aborted || ready(); });
+    if (aborted) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
+    if (!ok) {
+      aborted = true;
+      cv.notify_all();
+      throw DeviceError(PTW_ERR_HIP, std::string("timed out waiting for a peer (") + what +
+                                         "; PTW_COLLECTIVE_TIMEOUT_S): communicator aborted");
+    }
   }
 };
 
@@ -147,7 +178,10 @@ using namespace ptw;
 struct ptw_comm {
   ncclComm_t comm = nullptr;          // RCCL transport
   std::shared_ptr<LoopbackHub> hub;   // loopback transport (comm == nullptr)
-  std::vector<hipEvent_t> events;     // loopback: events this rank created (destroyed with it)
+  // loopback: one `ready` event per (destination, channel) and one `consumed` event per (source,
+  // channel), created on first use and re-recorded for every message - a long-lived communicator
+  // holds 4 x world events, however many collectives it has run
+  std::vector<hipEvent_t> events;
   int world = 1, rank = 0, device = 0;
   // packed rows of the gather: [rows][width][3] doubles then [rows][width] u32, per rank slot
   void *pack = nullptr;
@@ -155,30 +189,31 @@ struct ptw_comm {
   ~ptw_comm() {
     (void)hipSetDevice(device);
     if (pack) (void)hipFree(pack);
-    for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : events)
+      if (e) (void)hipEventDestroy(e);
     if (comm) (void)rccl().commDestroy(comm);
   }
-  hipEvent_t newEvent() {
-    hipEvent_t e = nullptr;
-    checkHip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
-    events.push_back(e);
+  hipEvent_t eventFor(int kind, int peer, int channel) { // kind 0: ready (send), 1: consumed (recv)
+    if (events.empty()) events.assign(static_cast<size_t>(world) * 4, nullptr);
+    hipEvent_t &e = events[(static_cast<size_t>(kind) * world + peer) * 2 + channel];
+    if (!e) checkHip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
     return e;
   }
   // ---- the two point-to-point primitives the collectives are written in -----------------------
   // (RCCL: ncclSend / ncclRecv inside the caller's group; loopback: see LoopbackHub)
   void loopSend(const void *ptr, size_t bytes, int dst, int channel, hipStream_t stream) {
-    const hipEvent_t ready = newEvent();
+    // (re-recording the event of the previous message to this peer is safe: that message reached
+    // state 2, i.e. the receiver's hipStreamWaitEvent on it has been issued)
+    const hipEvent_t ready = eventFor(0, dst, channel);
     checkHip(hipEventRecord(ready, stream), "hipEventRecord");
     hipEvent_t consumed = nullptr;
     {
       std::unique_lock<std::mutex> lock(hub->m);
       LoopMessage &msg = hub->at(rank, dst, channel);
-      hub->cv.wait(lock, [&] { return hub->aborted || msg.state == 0; });
-      if (hub->aborted) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
+      hub->await(lock, "send: slot free", [&] { return msg.state == 0; });
       msg.ptr = ptr, msg.bytes = bytes, msg.ready = ready, msg.state = 1;
       hub->cv.notify_all();
-      hub->cv.wait(lock, [&] { return hub->aborted || msg.state == 2; });
-      if (hub->aborted) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
+      hub->await(lock, "send: receiver", [&] { return msg.state == 2; });
       consumed = msg.consumed;
       msg = LoopMessage();
       hub->cv.notify_all();
@@ -193,16 +228,19 @@ struct ptw_comm {
     {
       std::unique_lock<std::mutex> lock(hub->m);
       LoopMessage &msg = hub->at(src, rank, channel);
-      hub->cv.wait(lock, [&] { return hub->aborted || msg.state == 1; });
-      if (hub->aborted) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
+      hub->await(lock, "receive: sender", [&] { return msg.state == 1; });
       got = msg;
     }
-    if (got.bytes != expectBytes)
+    if (got.bytes != expectBytes) {
+      hub->abort(); // the sender waits for this message to be consumed: release it
       throw DeviceError(PTW_ERR_SIZE_MISMATCH, "loopback message of " + std::to_string(got.bytes) +
                                                    " bytes where " + std::to_string(expectBytes) + " were expected");
+    }
     checkHip(hipStreamWaitEvent(stream, got.ready, 0), "hipStreamWaitEvent");
     consume(got.ptr, got.bytes);
-    const hipEvent_t consumed = newEvent();
+    // (the previous `consumed` event of this pair has been waited for by the sender's stream before
+    // the sender could post this message)
+    const hipEvent_t consumed = eventFor(1, src, channel);
     checkHip(hipEventRecord(consumed, stream), "hipEventRecord");
     {
       std::lock_guard<std::mutex> lock(hub->m);
@@ -310,6 +348,45 @@ int ptw_comm_abort(ptw_comm *comm) {
 }
 
 void ptw_comm_destroy(ptw_comm *comm) { delete comm; }
+
+int ptw_comm_wait(ptw_comm *comm, void *hip_stream, int32_t timeout_ms) {
+  if (!comm) return invalid("comm");
+  if (timeout_ms < 0) return invalid("timeout_ms");
+  PTW_GUARD_BEGIN
+  checkHip(hipSetDevice(comm->device), "hipSetDevice");
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  const auto deadline = std::chrono::steady_clock::now() + collectiveTimeout(timeout_ms);
+  auto giveUp = [&](const std::string &why) {
+    (void)ptw_comm_abort(comm); // ends the communicator's kernels on the device / wakes the rendezvous
+    throw DeviceError(PTW_ERR_HIP, why + ": communicator aborted");
+  };
+  for (unsigned spin = 0;; ++spin) {
+    const hipError_t q = hipStreamQuery(stream);
+    if (q == hipSuccess) return PTW_OK;
+    if (q != hipErrorNotReady) checkHip(q, "hipStreamQuery");
+    if (comm->hub) {
+      bool aborted;
+      {
+        std::lock_guard<std::mutex> lock(comm->hub->m);
+        aborted = comm->hub->aborted;
+      }
+      if (aborted) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
+    } else if (comm->comm) {
+      ncclResult_t async = ncclSuccess;
+      const ncclResult_t r = rccl().commGetAsyncError(comm->comm, &async);
+      if (r != ncclSuccess) giveUp(std::string("ncclCommGetAsyncError: ") + rccl().getErrorString(r));
+      if (async != ncclSuccess && async != ncclInProgress)
+        giveUp(std::string("asynchronous RCCL error: ") + rccl().getErrorString(async));
+    } else {
+      throw DeviceError(PTW_ERR_HIP, "communicator aborted");
+    }
+    if (std::chrono::steady_clock::now() >= deadline)
+      giveUp("the collective did not complete within the timeout (a peer that never arrived?)");
+    // a framebuffer collective takes well under a millisecond to a few: poll closely first
+    std::this_thread::sleep_for(std::chrono::microseconds(spin < 200 ? 50 : 1000));
+  }
+  PTW_GUARD_END
+}
 
 int ptw_comm_reduce_framebuffer(ptw_comm *comm, void *d_rgb_sum, void *d_counts, uint64_t npix,
                                 int32_t root, void *hip_stream) {

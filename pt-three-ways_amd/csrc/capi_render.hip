@@ -114,6 +114,9 @@ struct ptw_context {
   // Per-band staging buffer budget: npass x bandPix x 24 B.  4 GiB keeps the headline frame
   // (1024 x 1024 @ 256 spp = 6.4 GB staged) to two launches; the part has 288 GB.
   size_t stageBudgetBytes = size_t(4) << 30;
+  // contexts that share this device within one render (ptw_render_ex, share_device = 2): the clamp
+  // of the budget to the free memory is divided among them
+  int deviceShare = 1;
 
   void activate() const { check(hipSetDevice(device), "hipSetDevice"); }
   // Reads back and zeroes the per-pass ray counters (synchronous).
@@ -172,6 +175,9 @@ void validate(const ptw_render_params &p) {
       (p.row_stride <= 1 && p.row_phase != 0))
     throw std::invalid_argument("bad row_stride / row_phase");
   if (p.accel != PTW_ACCEL_NONE && p.accel != PTW_ACCEL_BVH) throw std::invalid_argument("unknown accel mode");
+  if (p.pix_kernel != PTW_PIX_KERNEL_AUTO && p.pix_kernel != PTW_PIX_KERNEL_LOCKSTEP &&
+      p.pix_kernel != PTW_PIX_KERNEL_PERSISTENT)
+    throw std::invalid_argument("unknown pix_kernel");
   if (p.accel != PTW_ACCEL_NONE && p.rng_policy != PTW_RNG_PERPIXEL)
     throw DeviceError(PTW_ERR_UNSUPPORTED,
                       "the accelerated mode needs PTW_RNG_PERPIXEL (the SEQUENTIAL kernels search the "
@@ -237,19 +243,16 @@ TraceParams makeTraceParams(const ptw_context &ctx, const ptw_camera &cam,
 
 // PERPIXEL policy: lock-step or persistent kernel (ptw_kernels.hip, launchTracePerPixel)?  Which
 // one is faster depends on how uniformly long the scene's paths are, which no host-side number
-// says: so the first large render of a scene + frame shape on a context times a trial of both -
-// about two million samples each, image rows spread over the whole frame, all passes' worth of
-// lanes - and the context remembers the winner.  The trial's outputs land in the staging buffer
-// (overwritten by the render) and nowhere else.  Renders below 16 M samples, A/B overrides
-// (PTW_PIX_KERNEL) and the accelerated mode do not calibrate.  This is the one place where
-// ptw_context_render waits for the device (a few tens of milliseconds, once).
-int choosePixKernel(ptw_context &ctx, const TraceParams &t, const TraceBuffers &b, const RowSet &rows,
-                    uint32_t bandPix, hipStream_t stream) {
-  if (std::getenv("PTW_PIX_KERNEL") || t.accel != PTW_ACCEL_NONE) return kPixKernelAuto;
-  const uint64_t total = static_cast<uint64_t>(rows.count) * t.width * t.npass;
-  if (total < (16ull << 20)) return kPixKernelAuto;
-  // FNV-1a over what the decision depends on
-  uint64_t key = 1469598103934665603ull;
+// says.  ptw_context_calibrate() times a trial of both - about two million samples each, image rows
+// spread over the whole frame, all passes' worth of lanes - and the context remembers the winner
+// under a key of what the decision depends on; PTW_PIX_KERNEL_AUTO resolves to it.  The trial's
+// outputs land in the staging buffer (overwritten by the next render) and nowhere else.
+// ptw_context_render never calibrates (it is asynchronous); ptw_render / ptw_render_ex do, once, for
+// renders of 16 M samples or more.
+constexpr uint64_t kCalibrateFromSamples = 16ull << 20;
+
+uint64_t pixChoiceKeyOf(const ptw_context &ctx, const TraceParams &t, const RowSet &rows) {
+  uint64_t key = 1469598103934665603ull; // FNV-1a
   auto mix = [&](const void *data, size_t n) {
     const unsigned char *c = static_cast<const unsigned char *>(data);
     for (size_t i = 0; i < n; ++i) key = (key ^ c[i]) * 1099511628211ull;
@@ -258,17 +261,33 @@ int choosePixKernel(ptw_context &ctx, const TraceParams &t, const TraceBuffers &
   mix(&t.cam, sizeof t.cam);
   const int32_t shape[7] = {t.width, t.height, t.maxDepth, t.fbU, t.fbV, t.preview, rows.stride};
   mix(shape, sizeof shape);
-  if (ctx.pixChoice != 0 && ctx.pixChoiceKey == key) return ctx.pixChoice;
+  return key;
+}
 
+// What PTW_PIX_KERNEL_AUTO means for this launch: the calibrated choice, else the persistent kernel.
+int resolvePixKernel(const ptw_context &ctx, const ptw_render_params &p, const TraceParams &t, const RowSet &rows) {
+  if (p.pix_kernel != PTW_PIX_KERNEL_AUTO) return p.pix_kernel;
+  if (ctx.pixChoice != 0 && ctx.pixChoiceKey == pixChoiceKeyOf(ctx, t, rows)) return ctx.pixChoice;
+  return kPixKernelPersistent;
+}
+
+// The timed trial (blocks until it has run).  `stageDoubles`: capacity of b.stage.
+int calibratePixKernel(ptw_context &ctx, const TraceParams &t, const TraceBuffers &b, const RowSet &rows,
+                       size_t stageDoubles, hipStream_t stream) {
+  if (t.accel != PTW_ACCEL_NONE || t.rngPolicy != PTW_RNG_PERPIXEL || rows.count == 0 || t.npass == 0)
+    return kPixKernelAuto;
   TraceParams tt = t;
   tt.npass = std::min<uint32_t>(t.npass, 32);
   uint32_t trialRows = static_cast<uint32_t>(std::max<uint64_t>(1, (2ull << 20) / (static_cast<uint64_t>(t.width) * tt.npass)));
   trialRows = std::min<uint32_t>(trialRows, static_cast<uint32_t>(rows.count));
-  trialRows = std::min<uint32_t>(trialRows, std::max<uint32_t>(1, bandPix / static_cast<uint32_t>(t.width)));
   tt.rowFirst = rows.first;
   tt.rowStride = rows.stride * std::max<int>(1, rows.count / static_cast<int>(trialRows)); // spread over the frame
   tt.pixBegin = 0;
-  tt.pixCount = trialRows * static_cast<uint32_t>(t.width);
+  // The trial writes tt.npass x tt.pixCount x 3 doubles of staged radiance: never more than the
+  // staging buffer holds (a tiny staging budget can leave less than one image row per pass).
+  const uint64_t fits = stageDoubles / (3ull * tt.npass);
+  tt.pixCount = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(trialRows) * static_cast<uint32_t>(t.width), fits));
+  if (tt.pixCount == 0) return kPixKernelAuto;
   TraceBuffers bb = b;
   bb.rays = nullptr;  // the trial is not part of the render's statistics
   bb.words = nullptr;
@@ -295,21 +314,24 @@ int choosePixKernel(ptw_context &ctx, const TraceParams &t, const TraceBuffers &
     throw;
   }
   for (auto &e : ev) (void)hipEventDestroy(e);
-  ctx.pixChoiceKey = key;
+  ctx.pixChoiceKey = pixChoiceKeyOf(ctx, t, rows);
   ctx.pixChoice = ms[0] < ms[1] ? kPixKernelLockstep : kPixKernelPersistent;
   if (std::getenv("PTW_PIX_TRACE"))
-    std::fprintf(stderr, "ptw: PERPIXEL trial (%u rows x %d x %u passes): lock-step %.3f ms, persistent %.3f ms -> %s\n",
-                 trialRows, t.width, tt.npass, ms[0], ms[1], ctx.pixChoice == kPixKernelLockstep ? "lock-step" : "persistent");
+    std::fprintf(stderr, "ptw: PERPIXEL trial (%u pixels x %u passes): lock-step %.3f ms, persistent %.3f ms -> %s\n",
+                 tt.pixCount, tt.npass, ms[0], ms[1], ctx.pixChoice == kPixKernelLockstep ? "lock-step" : "persistent");
   return ctx.pixChoice;
 }
 
 // Enqueues the whole render on `stream`.  `betweenBands`, when set, is called after each
 // band's launches have been enqueued with the band's local pixel range and the samples enqueued so
 // far; returning true cancels.  `minBands` > 1 cuts the frame into at least that many bands.
+// `calibrate`: nullptr - render; otherwise nothing is rendered: the PERPIXEL kernel trial runs on the
+// buffers the render would use and *calibrate receives the winner (ptw_context_calibrate).
 template <typename BetweenBands>
 void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_params &p,
                    double *dRgb, uint32_t *dCounts, uint32_t *dWords, hipStream_t stream,
-                   int minBands, BetweenBands &&betweenBands) {
+                   int minBands, BetweenBands &&betweenBands, int *calibrate = nullptr) {
+  if (calibrate) *calibrate = kPixKernelAuto;
   validate(p);
   if (!ctx.haveScene) throw std::invalid_argument("no scene set on this context");
   ctx.activate();
@@ -332,7 +354,8 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
     size_t freeB = 0, totalB = 0;
     if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
       const size_t held = ctx.stage.capacity * sizeof(double);
-      budget = std::min(budget, std::max<size_t>((freeB + held) / 2, size_t(1) << 20));
+      const size_t share = static_cast<size_t>(std::max(1, ctx.deviceShare));
+      budget = std::min(budget, std::max<size_t>((freeB / share + held) / 2, size_t(1) << 20));
     }
   }
   uint64_t bandPix = budget / (static_cast<uint64_t>(npass) * 24);
@@ -364,6 +387,7 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
     check(hipDeviceSynchronize(), "hipDeviceSynchronize");
   }
 
+  if (calibrate && sequential) return;
   if (sequential) {
     // std::mt19937 rng(seed + curSample++), Scene.cpp:211: seed the generators on the host
     if (ctx.uploadsDone) // an earlier render's upload may still be reading the host vectors
@@ -427,7 +451,11 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
     ctx.timed.push_back(ev);
   };
 
-  if (!sequential) t.pixKernel = choosePixKernel(ctx, t, b, rows, static_cast<uint32_t>(bandPix), stream);
+  if (calibrate) {
+    *calibrate = calibratePixKernel(ctx, t, b, rows, ctx.stage.capacity, stream);
+    return;
+  }
+  if (!sequential) t.pixKernel = resolvePixKernel(ctx, p, t, rows);
 
   uint64_t done = 0;
   for (uint32_t begin = 0; begin < pixTotal;) {
@@ -524,6 +552,18 @@ int ptw_context_render(ptw_context *ctx, const ptw_camera *camera, const ptw_ren
                 static_cast<uint32_t *>(d_counts), static_cast<uint32_t *>(d_words),
                 static_cast<hipStream_t>(hip_stream), 0,
                 [](const TraceParams &, uint64_t, uint64_t) { return false; });
+  return PTW_OK;
+  PTW_GUARD_END
+}
+
+int ptw_context_calibrate(ptw_context *ctx, const ptw_camera *camera, const ptw_render_params *params,
+                          void *hip_stream, int32_t *kernel_out) {
+  if (!ctx || !camera || !params) return invalid("null pointer");
+  PTW_GUARD_BEGIN
+  int choice = kPixKernelAuto;
+  enqueueRender(*ctx, *camera, *params, nullptr, nullptr, nullptr, static_cast<hipStream_t>(hip_stream), 0,
+                [](const TraceParams &, uint64_t, uint64_t) { return false; }, &choice);
+  if (kernel_out) *kernel_out = choice;
   return PTW_OK;
   PTW_GUARD_END
 }
@@ -632,6 +672,17 @@ int ptw_render(const ptw_scene_view *scene, const ptw_camera *camera,
 
 namespace {
 
+// ptw_render / ptw_render_ex are synchronous calls: a PERPIXEL render of 16 M samples or more whose
+// caller left the kernel choice open first times the trial (ptw_context_calibrate).
+bool wantsCalibration(const ptw_render_params &p) {
+  if (p.rng_policy != PTW_RNG_PERPIXEL || p.pix_kernel != PTW_PIX_KERNEL_AUTO || p.accel != PTW_ACCEL_NONE)
+    return false;
+  if (std::getenv("PTW_PIX_KERNEL")) return false; // A/B override of the launcher
+  const uint64_t samples = static_cast<uint64_t>(rowsOf(p).count) * static_cast<uint64_t>(p.width) *
+                           static_cast<uint64_t>(std::max(0, p.samples_per_pixel));
+  return samples >= kCalibrateFromSamples;
+}
+
 // One device's share of a ptw_render_ex call: its own context (one scene upload), its own
 // stream, device-resident framebuffer.
 struct DeviceShard {
@@ -679,7 +730,14 @@ void renderSingle(const ptw_scene_view &scene, const ptw_camera &camera,
   // With a callback the frame is cut into bands so that there is something to report: 20 for
   // the 5 % steps of the reference's Progressifier, `min_updates` for snapshots.
   const int minBands = opt.update ? (opt.min_updates > 0 ? opt.min_updates : 16) : (opt.progress ? 20 : 0);
-  enqueueRender(*ctx, camera, params, dRgb.ptr, dCounts.ptr, nullptr, nullptr, minBands,
+  ptw_render_params rp = params;
+  if (wantsCalibration(rp)) {
+    int32_t choice = PTW_PIX_KERNEL_AUTO;
+    if (int rc = ptw_context_calibrate(ctx.get(), &camera, &rp, nullptr, &choice); rc != PTW_OK)
+      throw DeviceError(rc, ptw_last_error());
+    rp.pix_kernel = choice;
+  }
+  enqueueRender(*ctx, camera, rp, dRgb.ptr, dCounts.ptr, nullptr, nullptr, minBands,
                 [&](const TraceParams &t, uint64_t done, uint64_t total) {
                   if (!talk) return false;
                   check(hipStreamSynchronize(nullptr), "band");
@@ -793,6 +851,27 @@ void renderMulti(const ptw_scene_view &scene, const ptw_camera &camera,
     return v && *v ? std::atoi(v) : -1;
   };
   const int failSetup = envShard("PTW_TEST_FAIL_SHARD"), failCollective = envShard("PTW_TEST_FAIL_COLLECTIVE");
+  // PTW_TEST_SILENT_SHARD=g: shard g reports success WITHOUT entering the collective - the in-process
+  // picture of a peer that dies after the others have enqueued theirs; the watchdog must end it.
+  const int silentShard = envShard("PTW_TEST_SILENT_SHARD");
+
+  // The PERPIXEL kernel choice is made ONCE, on the first shard's context, and handed to every
+  // shard: all of them run the same kernel (two shards that each timed their own trial could pick
+  // differently - same bytes, different speed, and the gather waits for the slower one).
+  auto makeContext = [&](DeviceShard &sh) {
+    ptw_context *raw = nullptr;
+    if (ptw_context_create(sh.device, &raw) != PTW_OK) throw DeviceError(PTW_ERR_NO_DEVICE, ptw_last_error());
+    sh.ctx.reset(raw);
+    if (opt.share_device) raw->deviceShare = n;
+    if (int rc = ptw_context_set_scene(sh.ctx.get(), &scene); rc != PTW_OK) throw DeviceError(rc, ptw_last_error());
+  };
+  if (wantsCalibration(shards[0].params) && failSetup != 0) {
+    makeContext(shards[0]);
+    int32_t choice = PTW_PIX_KERNEL_AUTO;
+    if (int rc = ptw_context_calibrate(shards[0].ctx.get(), &camera, &shards[0].params, nullptr, &choice); rc != PTW_OK)
+      throw DeviceError(rc, ptw_last_error());
+    for (DeviceShard &sh : shards) sh.params.pix_kernel = choice;
+  }
 
   // ---- phase 1, one host thread per device: context + scene upload, the render, and its
   // completion.  No collective yet: a shard that fails here has no peer waiting for it. ----
@@ -804,10 +883,8 @@ void renderMulti(const ptw_scene_view &scene, const ptw_camera &camera,
         DeviceShard &sh = shards[g];
         guarded(sh, [&] {
           if (g == failSetup) throw DeviceError(PTW_ERR_HIP, "injected failure (PTW_TEST_FAIL_SHARD)");
-          ptw_context *raw = nullptr;
-          if (ptw_context_create(sh.device, &raw) != PTW_OK) throw DeviceError(PTW_ERR_NO_DEVICE, ptw_last_error());
-          sh.ctx.reset(raw);
-          if (int rc = ptw_context_set_scene(sh.ctx.get(), &scene); rc != PTW_OK) throw DeviceError(rc, ptw_last_error());
+          if (!sh.ctx) makeContext(sh);
+          sh.ctx->activate();
           check(hipStreamCreateWithFlags(&sh.stream, hipStreamNonBlocking), "hipStreamCreate");
           sh.rgb.reserve(npix * 3);
           sh.counts.reserve(npix);
@@ -849,10 +926,11 @@ void renderMulti(const ptw_scene_view &scene, const ptw_camera &camera,
     throw std::invalid_argument("cancelled by the callback");
   }
 
-  // ---- phase 2: the one collective, entered by every shard (all of them are healthy).  A shard
-  // whose call fails aborts its communicator, which releases the peers (loopback: the host
-  // rendezvous; RCCL: after the join below every communicator is aborted, which ends the kernels
-  // that wait for the missing peer on the device). ----
+  // ---- phase 2: the one collective, entered by every shard (all of them are healthy), and its
+  // completion under the watchdog (ptw_comm_wait).  A shard whose call fails, or whose wait ends with
+  // an asynchronous RCCL error or the timeout - a peer that never arrived -, aborts its communicator,
+  // which releases the peers (loopback: the host rendezvous; RCCL: ncclCommAbort ends the kernels
+  // that wait for the missing peer on the device); after the join every communicator is aborted. ----
   {
     std::vector<std::thread> threads;
     for (int g = 0; g < n; ++g)
@@ -862,12 +940,15 @@ void renderMulti(const ptw_scene_view &scene, const ptw_camera &camera,
         if (g == failCollective) {
           rc = PTW_ERR_HIP;
           sh.error = "injected failure (PTW_TEST_FAIL_COLLECTIVE)";
+        } else if (g == silentShard) {
+          return; // (test hook: this shard never shows up)
         } else {
           if (sequential)
             rc = ptw_comm_reduce_framebuffer(comms[g], sh.rgb.ptr, sh.counts.ptr, npix, 0, sh.stream);
           else
             rc = ptw_comm_gather_rows(comms[g], sh.rgb.ptr, sh.counts.ptr, params.width, params.height, 0,
                                       sh.stream);
+          if (rc == PTW_OK) rc = ptw_comm_wait(comms[g], sh.stream, 0);
           if (rc != PTW_OK) sh.error = ptw_last_error();
         }
         if (rc != PTW_OK) {
@@ -880,7 +961,7 @@ void renderMulti(const ptw_scene_view &scene, const ptw_camera &camera,
   if (const DeviceShard *bad = firstFailure()) {
     // report the shard that failed on its own, not a peer that was released by the abort
     for (const DeviceShard &sh : shards)
-      if (sh.status != PTW_OK && sh.error.find("aborted") == std::string::npos) {
+      if (sh.status != PTW_OK && sh.error.find("communicator aborted") != 0) {
         bad = &sh;
         break;
       }
@@ -888,10 +969,6 @@ void renderMulti(const ptw_scene_view &scene, const ptw_camera &camera,
     const std::string message = "device " + std::to_string(bad->device) + ": " + bad->error;
     abortAll();
     throw DeviceError(status, message);
-  }
-  for (DeviceShard &sh : shards) {
-    check(hipSetDevice(sh.device), "hipSetDevice");
-    check(hipStreamSynchronize(sh.stream), "collective");
   }
   check(hipSetDevice(shards[0].device), "hipSetDevice");
   check(hipMemcpy(rgbSum, shards[0].rgb.ptr, npix * 3 * sizeof(double), hipMemcpyDeviceToHost), "D2H");

@@ -111,5 +111,10 @@ class FrameComm:
         h, w = counts.shape
         self.comm.gather_rows(rgb_sum.data_ptr(), counts.data_ptr(), w, h, dst, stream)
 
+    def wait(self, stream: int = 0, timeout_ms: int = 0) -> None:
+        """Completion of the collectives enqueued on `stream` under the library's watchdog
+        (ptw_comm_wait): a peer that died after its enqueue is an error, not a hang."""
+        self.comm.wait(stream, timeout_ms)
+
     def close(self):
         self.comm.close()

@@ -380,35 +380,92 @@ def test_reference_side_binding_runs_on_the_gpu(pkg, scene, w, h, spp):
     assert int(proc.stdout.split("updates=")[1].split()[0]) >= 2
 
 
-@pytest.mark.parametrize("name,want", [("cornell", "tracePerPixel"), ("bbc-owl", "tracePerPixelPersistent")])
-def test_perpixel_kernel_is_chosen_by_a_timed_trial(pkg, name, want):
-    """PERPIXEL policy: a render of 16 M samples or more times a trial of the lock-step and the
-    persistent kernel once per scene + frame shape and runs the faster one - the lock-step kernel in
-    the closed Cornell box (measured 224 against 146 Msamples/s at the BASELINE shape), the persistent
-    one in open scenes (bbc-owl 395 against 139).  Small renders do not calibrate.  Whichever runs,
-    the bytes are the same (tests/test_gpu_cli.py compares the kernels' .raw files)."""
+@pytest.mark.parametrize("name", ["cornell", "bbc-owl"])
+def test_perpixel_kernel_choice_is_explicit(pkg, monkeypatch, name):
+    """PERPIXEL policy (ABI v4): ptw_context_render never waits for the device - PTW_PIX_KERNEL_AUTO is
+    the persistent kernel until ptw_context_calibrate() has timed the two kernels on this scene +
+    frame shape; afterwards AUTO is the measured winner, and ptw_render_params.pix_kernel overrides
+    either way.  Which kernel wins is a property of the box and its load: the test checks
+    that ONE was chosen, reported, reused and really ran, that the trial stays out of the statistics
+    and out of the image, and that both kernels write the same bytes."""
     import torch
-    w = h = 512
+    w = h = 256
     scene = pkg.Scene()
     cam = scene.build_named(name, w, h)
     ctx = pkg.Context(0)
     ctx.set_scene(scene)
     ctx.enable_stats(True)
-    rgb = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
-    cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    small = pkg.default_params(width=w, height=h, samples_per_pixel=2, seed=1, rng_policy=1)
-    ctx.render(cam, small, rgb.data_ptr(), cnt.data_ptr(), 0, stream)
-    torch.cuda.synchronize()
-    assert ctx.stats(reset=True).trace_kernel.decode() == "tracePerPixelPersistent"
-    big = pkg.default_params(width=w, height=h, samples_per_pixel=64, seed=1, rng_policy=1)
-    for _ in range(2):      # the second render reuses the decision
-        ctx.render(cam, big, rgb.data_ptr(), cnt.data_ptr(), 0, stream)
+
+    def run(params):
+        rgb = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+        cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+        ctx.render(cam, params, rgb.data_ptr(), cnt.data_ptr(), 0, stream)
         torch.cuda.synchronize()
         st = ctx.stats(reset=True)
-        assert st.trace_kernel.decode() == want
-        assert st.samples == w * h * 64 and st.rays > 0      # the trial is not in the statistics
-    assert int(cnt.min().item()) == 2 + 128 and int(cnt.max().item()) == 2 + 128
+        assert st.samples == w * h * params.samples_per_pixel and st.rays > 0
+        assert int(cnt.min().item()) == params.samples_per_pixel == int(cnt.max().item())
+        return rgb.cpu().numpy(), st.trace_kernel.decode()
+
+    auto = pkg.default_params(width=w, height=h, samples_per_pixel=8, seed=1, rng_policy=1)
+    before, kernel = run(auto)
+    assert kernel == "tracePerPixelPersistent"          # nothing calibrated yet
+    names = {pkg.PIX_KERNEL_LOCKSTEP: "tracePerPixel", pkg.PIX_KERNEL_PERSISTENT: "tracePerPixelPersistent"}
+    choice = ctx.calibrate(cam, auto, stream)
+    assert choice in names
+    ctx.stats(reset=True)                                # (the trial's launches are not a render's)
+    for _ in range(2):                                   # AUTO now means the winner, every time
+        after, kernel = run(auto)
+        assert kernel == names[choice]
+        assert np.array_equal(after, before)             # same bytes whichever kernel ran
+    for forced, want in names.items():                   # the caller's explicit choice wins
+        p = pkg.default_params(width=w, height=h, samples_per_pixel=8, seed=1, rng_policy=1, pix_kernel=forced)
+        img, kernel = run(p)
+        assert kernel == want and np.array_equal(img, before)
+    # another frame shape has not been calibrated: AUTO is the persistent kernel there
+    other = pkg.default_params(width=w, height=h, samples_per_pixel=8, seed=1, rng_policy=1, row_stride=2, row_phase=1)
+    rgb = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+    cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    ctx.render(cam, other, rgb.data_ptr(), cnt.data_ptr(), 0, stream)
+    torch.cuda.synchronize()
+    assert ctx.stats(reset=True).trace_kernel.decode() == "tracePerPixelPersistent"
+    # the sequential policy has nothing to calibrate
+    assert ctx.calibrate(cam, pkg.default_params(width=w, height=h, samples_per_pixel=8, seed=1), stream) == pkg.PIX_KERNEL_AUTO
+
+
+def test_calibration_trial_fits_a_tiny_staging_buffer(pkg, monkeypatch):
+    """with a staging budget below one image row per pass the trial used to write
+    past the end of the staging buffer.  It is clamped to what the buffer holds; the render that
+    follows (many bands) still equals the render without a budget."""
+    import torch
+    w, h, spp = 1024, 16, 16
+    scene = pkg.Scene()
+    cam = scene.build_named("cornell", w, h)
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=2, rng_policy=1)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(budget_kb):
+        if budget_kb:
+            monkeypatch.setenv("PTW_STAGE_BUDGET_KB", str(budget_kb))
+        else:
+            monkeypatch.delenv("PTW_STAGE_BUDGET_KB", raising=False)
+        ctx = pkg.Context(0)
+        ctx.set_scene(scene)
+        guard = torch.full((1 << 20,), 7.0, dtype=torch.float64, device="cuda")  # neighbours of the staging buffer
+        choice = ctx.calibrate(cam, params, stream)
+        rgb = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+        cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+        p = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=2, rng_policy=1,
+                               pix_kernel=pkg.PIX_KERNEL_PERSISTENT)
+        ctx.render(cam, p, rgb.data_ptr(), cnt.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+        assert bool((guard == 7.0).all().item())
+        return choice, rgb.cpu().numpy(), cnt.cpu().numpy()
+
+    c_small, rgb_small, cnt_small = run(24)   # 24 KB: 64 pixels per band, less than a row of 1024
+    c_full, rgb_full, cnt_full = run(None)
+    assert c_small in (pkg.PIX_KERNEL_LOCKSTEP, pkg.PIX_KERNEL_PERSISTENT) and c_full in (1, 2)
+    assert np.array_equal(rgb_small, rgb_full) and np.array_equal(cnt_small, cnt_full)
 
 
 # ---- several CUs per pass (traceSequentialGang; experiments build only) ---------------------------

@@ -1,0 +1,218 @@
+"""GPU: round-4 additions - the multi-GPU path made executable on ONE GPU, and cfg5's shape.
+
+* `bench.py --gpus 2` WITHOUT torchrun launches its two ranks itself (round 3 degraded to one GPU
+  with a warning); on a one-GPU box the two ranks share the device (PTW_BENCH_SHARE_GPU=1: each rank
+  its own NCCL_HOSTID, RCCL's socket transport) - Shard pass / row split, FrameComm, the reduce, the
+  gather of the per-pixel leg, `scaling_expected`, `value_tile_sharded` all execute with world = 2,
+  and the images equal the one-rank images;
+* BASELINE cfg5's shape (4096 x 4096, 8 shards) through ptw_render_ex(num_devices = 8,
+  share_device = 2): the interleaved-row gather of the full 462 MB frame, and eight pass shards +
+  reduce on a 4096 x 64 prefix;
+* the collectives' watchdog (ptw_comm_wait / the loopback rendezvous' timeout): a shard that never
+  enters the collective, and an RCCL peer that exits, end in PTW_ERR_HIP - not in a hang.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench(args, env_extra, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True,
+                          timeout=timeout, cwd=ROOT, env=env)
+    return proc
+
+
+def _line(proc):
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout
+    assert len(lines[0]) < 6000, f"bench line of {len(lines[0])} bytes: the driver's record would cut it"
+    return json.loads(lines[0])
+
+
+SMALL = ["--width", "48", "--height", "40", "--spp", "12", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+         "--no-parity"]
+
+
+@pytest.mark.parametrize("policy", ["sequential", "perpixel"])
+def test_bench_gpus_2_launches_itself_two_ranks_on_one_gpu(pkg, tmp_path, policy):
+    """VERDICT r3 next-1 (a, b): `python bench.py --gpus 2` with no RANK in the environment runs TWO
+    ranks (n_gpus 2, rccl_ranks 2) and its image is the one-rank image."""
+    one_raw, two_raw = str(tmp_path / "one.raw"), str(tmp_path / "two.raw")
+    one = _line(_bench([*SMALL, "--policy", policy, "--dump-raw", one_raw], {}))
+    assert one["n_gpus"] == 1 and one["rccl_ranks"] == 1 and "scaling_expected" not in one
+    proc = _bench([*SMALL, "--gpus", "2", "--policy", policy, "--dump-raw", two_raw],
+                  {"PTW_BENCH_SHARE_GPU": "1", "NCCL_DEBUG": "WARN", "PTW_COLLECTIVE_TIMEOUT_S": "120"})
+    if proc.returncode != 0 and "Duplicate GPU detected" in proc.stderr:
+        pytest.skip("RCCL refused two ranks on one GPU despite NCCL_HOSTID: " + proc.stderr[-800:])
+    two = _line(proc)
+    assert two["n_gpus"] == 2 and two["rccl_ranks"] == 2 and two["scaling"] == "strong"
+    assert two["config"]["spp_this_rank"] == (6 if policy == "sequential" else 12)
+    exp = two["scaling_expected"]
+    assert exp["value_policy"] == policy and exp["sequential"]["passes_per_gpu"] == 6
+    assert exp["sequential"]["expected_speedup_vs_1gpu"] == 1.0
+    if policy == "sequential":
+        pp = two["perpixel_policy"]
+        assert pp["n_gpus"] == 2 and pp["frame_complete_on_root"] is True
+        assert two["value_tile_sharded"] == pp["value"]
+    else:
+        assert two["value_tile_sharded"] == two["value"]
+    a_rgb, a_cnt = pkg.raw_load(one_raw)
+    b_rgb, b_cnt = pkg.raw_load(two_raw)
+    assert np.array_equal(a_cnt, b_cnt) and np.all(b_cnt == 12)
+    if policy == "perpixel":
+        assert np.array_equal(a_rgb, b_rgb)          # a gather moves bytes
+    else:                                            # two pass ranges added in another order
+        assert float(np.max(np.abs(a_rgb - b_rgb) / np.maximum(np.abs(a_rgb), 1.0))) < 1e-14
+
+
+def test_bench_refuses_more_ranks_than_gpus_without_the_switch():
+    """... and without PTW_BENCH_SHARE_GPU it says so instead of quietly rendering on one GPU."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    proc = _bench([*SMALL, "--gpus", str(n)], {})
+    assert proc.returncode == 2 and "GPU(s) are visible" in proc.stderr and "{" not in proc.stdout
+
+
+def test_cfg5_shape_tile_sharded_gather_of_the_full_frame(pkg):
+    """BASELINE cfg5's shape under the tile-sharded policy: 4096 x 4096, image rows interleaved over
+    EIGHT shards (row_stride 8), each with its own host thread, context, stream and device-resident
+    frame, assembled by ONE gather of the full 462 MB framebuffer (loopback transport in place of
+    RCCL: one GPU) - at 1 spp; every count 1, bytes equal to the single-device render."""
+    w = h = 4096
+    scene = pkg.Scene()
+    cam = scene.build_named("cornell", w, h)
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=1, seed=1, rng_policy=pkg.RNG_PERPIXEL)
+    one_rgb, one_cnt = pkg.render(scene, cam, params)
+    many_rgb, many_cnt = pkg.render(scene, cam, params, num_devices=8, share_device=2)
+    assert np.all(many_cnt == 1) and np.array_equal(many_cnt, one_cnt)
+    assert np.array_equal(many_rgb, one_rgb)
+    assert float(one_rgb.sum()) > 0
+
+
+def test_cfg5_shape_pass_sharded_reduce_on_a_prefix(pkg):
+    """... and under the seed-matched policy: eight pass shards of one pass each on a 4096 x 64 prefix
+    of the 4096 x 4096 frame + ONE reduce(sum) of the full-size framebuffer (462 MB per shard)."""
+    w = h = 4096
+    scene = pkg.Scene()
+    cam = scene.build_named("cornell", w, h)
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=8, seed=1, row_begin=0, row_end=64)
+    one_rgb, one_cnt = pkg.render(scene, cam, params)
+    many_rgb, many_cnt = pkg.render(scene, cam, params, num_devices=8, share_device=2)
+    assert np.array_equal(many_cnt, one_cnt) and np.all(many_cnt[:64] == 8) and not many_cnt[64:].any()
+    assert float(np.max(np.abs(many_rgb - one_rgb) / np.maximum(np.abs(one_rgb), 1.0))) < 1e-14
+    assert not many_rgb[64:].any()
+
+
+SILENT_SCRIPT = r"""
+import sys, time
+sys.path.insert(0, {root!r})
+import torch  # noqa: F401  (one HIP runtime per process)
+import __graft_entry__ as entry
+pkg = entry.load_package()
+scene = pkg.Scene()
+cam = scene.build_named("cornell", 16, 12)
+params = pkg.default_params(width=16, height=12, samples_per_pixel=4, seed=1, rng_policy={policy})
+t0 = time.time()
+try:
+    pkg.render(scene, cam, params, num_devices={n}, share_device=2)
+except pkg.PtwError as e:
+    print("PTW_ERROR", e.status, "after %.1f s" % (time.time() - t0), e)
+    sys.exit(0)
+print("NO_ERROR")
+sys.exit(3)
+"""
+
+
+@pytest.mark.parametrize("silent,policy,n", [(1, 0, 2), (0, 1, 3), (2, 1, 3)])
+def test_shard_that_never_enters_the_collective_times_out(tmp_path, silent, policy, n):
+    """phase 2 of renderMulti handled a collective call that RETURNS an error; a peer
+    that simply never shows up (the in-process picture of a rank that dies after the others have
+    enqueued) left everybody waiting.  Now the wait is bounded (PTW_COLLECTIVE_TIMEOUT_S), the
+    communicator is aborted, and the render ends with PTW_ERR_HIP."""
+    script = tmp_path / "silent.py"
+    script.write_text(SILENT_SCRIPT.format(root=str(ROOT), policy=policy, n=n))
+    env = dict(os.environ, PTW_TEST_SILENT_SHARD=str(silent), PTW_COLLECTIVE_TIMEOUT_S="3")
+    proc = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=120)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    assert "PTW_ERROR 3" in proc.stdout and "timed out" in proc.stdout, proc.stdout
+
+
+PEER_EXIT_SCRIPT = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+rank, uid_file, w, h = int(sys.argv[1]), sys.argv[2], 9, 7
+import torch
+import __graft_entry__ as entry
+pkg = entry.load_package()
+if rank == 0:
+    uid = pkg.Comm.unique_id()
+    with open(uid_file + ".tmp", "wb") as f:
+        f.write(uid)
+    os.replace(uid_file + ".tmp", uid_file)
+else:
+    t0 = time.time()
+    while not os.path.exists(uid_file):
+        if time.time() - t0 > 60:
+            print("NO_UID"); sys.exit(4)
+        time.sleep(0.05)
+    uid = open(uid_file, "rb").read()
+try:
+    comm = pkg.Comm.create(uid, 2, rank, 0)
+except pkg.PtwError as e:
+    print("RCCL_REFUSED", e); sys.exit(0)
+print("COMM_UP", rank, flush=True)
+if rank == 1:
+    time.sleep(1.0)
+    os._exit(0)          # dies with the collective outstanding on rank 0
+rgb = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+stream = torch.cuda.current_stream().cuda_stream
+comm.gather_rows(rgb.data_ptr(), cnt.data_ptr(), w, h, 0, stream)   # enqueued: waits for rank 1's rows
+t0 = time.time()
+try:
+    comm.wait(stream, 10000)
+    print("NO_ERROR")
+except pkg.PtwError as e:
+    print("WATCHDOG_OK status", e.status, "after %.1f s:" % (time.time() - t0), e, flush=True)
+os._exit(0)              # (no teardown of a communicator whose peer is gone)
+"""
+
+
+def test_rccl_peer_that_exits_is_an_error_not_a_hang(tmp_path):
+    """The same on the RCCL transport, two processes on one GPU (NCCL_HOSTID, socket transport): rank 1
+    exits without sending; rank 0's gather is enqueued and ptw_comm_wait - polling
+    ncclCommGetAsyncError and a deadline around the stream - returns PTW_ERR_HIP."""
+    script = tmp_path / "peer.py"
+    script.write_text(PEER_EXIT_SCRIPT.format(root=str(ROOT)))
+    uid_file = str(tmp_path / "uid.bin")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, NCCL_HOSTID=f"ptw-test-host-{r}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1",
+                   NCCL_P2P_DISABLE="1", NCCL_SHM_DISABLE="1", NCCL_DEBUG="WARN", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script), str(r), uid_file], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=150)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("the watchdog did not end the wait within 150 s")
+        outs.append(out)
+    text = "\n".join(outs)
+    if "RCCL_REFUSED" in text or "COMM_UP 0" not in text:
+        pytest.skip("RCCL refused two ranks on one GPU: " + text[-600:])
+    assert "WATCHDOG_OK status 3" in text and "NO_ERROR" not in text, text
