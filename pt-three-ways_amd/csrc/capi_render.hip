@@ -238,6 +238,7 @@ TraceParams makeTraceParams(const ptw_context &ctx, const ptw_camera &cam,
   t.rowFirst = 0;
   t.rowStride = 1;
   t.accel = p.accel;
+  if (const char *v = std::getenv("PTW_PIX_COUNT_SLOTS")) t.padA = v[0] == '1'; // (read by the prof build only)
   return t;
 }
 

@@ -2138,6 +2138,15 @@ struct PixCtxT {
   }
 
   __device__ __forceinline__ HitKey intersect(d3 o, d3 d) {
+#if PTW_PROFILE_PHASES
+    // PTW_PIX_COUNT_SLOTS=1 (prof build): count lane SLOTS instead of rays - 64 per call of this
+    // function by a wave, whatever the number of lanes that still hold a ray: rays / slots is the
+    // lane occupancy of the lock-step kernel
+    if (p->padA) {
+      const unsigned long long exec = __builtin_amdgcn_ballot_w64(true);
+      if (static_cast<int>(threadIdx.x & 63) == __builtin_ctzll(exec)) rays += 64;
+    } else
+#endif
     rays++;
     HitKey key;
     key.t = kInf, key.idx = kMiss, key.det = 0;
@@ -2232,6 +2241,11 @@ __device__ __forceinline__ d3 radiance0Pix(PixCtxT<BVH> &ctx, const TraceParams 
 template <bool BVH>
 __device__ __forceinline__ void perPixelSample(const TraceParams &p, const TraceBuffers &b, uint32_t *ldsWords) {
   const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
+  // intersect() calls of all of this lane's samples: ONE atomic per wave at the end (the address is
+  // wave-uniform, so the compiler reduces the 64 lanes first).  Round 3 added each sample's count to
+  // its pass's counter - a 32-byte memory request per sample, 2.8x the path's algorithmic HBM
+  // traffic; only the sum over the passes is ever read (ptw_context_get_stats).
+  unsigned long long laneRays = 0;
   // grid-stride: a lane traces sample gid, gid + grid, ... one after another (launchTracePerPixel
   // sizes the grid for kPixSamplesPerLane samples per lane; 1 = one sample per lane per launch)
   for (uint64_t gid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; gid < total;
@@ -2275,8 +2289,9 @@ __device__ __forceinline__ void perPixelSample(const TraceParams &p, const Trace
   double *out = b.stage + (static_cast<size_t>(pass) * p.pixCount + i) * 3;
   out[0] = L.x, out[1] = L.y, out[2] = L.z;
   if (b.words) b.words[static_cast<size_t>(pass) * p.npix + pix] = ctx.words;
-  if (b.rays) atomicAdd(&b.rays[pass], ctx.rays);
+  laneRays += ctx.rays;
   }
+  if (b.rays) atomicAdd(&b.rays[0], laneRays);
 }
 
 __global__ __launch_bounds__(kPixBlock) __attribute__((amdgpu_waves_per_eu(PTW_PIX_WAVES, PTW_PIX_WAVES))) void tracePerPixel(
