@@ -28,7 +28,7 @@ N > 1 (one process per GPU): STRONG scaling of the same frame by default (`--sca
 `--config cfg3|cfg4` selects the other single-GPU BASELINE configurations (suzanne 1024x1024 @ 512
 spp; ce 2048x2048 @ 1024 spp as a stated prefix sub-run of the frame) with the same JSON contract;
 the default cfg2 line also carries both, measured once each in the same run, as `other_configs`,
-and the strict-IEEE build's headline number as `strict_fp`.
+and the no-contraction (exact-decisions) build's headline number as `strict_fp`.
 
 `python bench.py --gpus N` WITHOUT torch.distributed.run around it launches the N ranks itself
 (re-executes under `python -m torch.distributed.run --nproc-per-node N`): the line always carries
@@ -97,7 +97,7 @@ def parse_args():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default cfg2 run: skip the one-shot cfg3 / cfg4 measurements (`other_configs`)")
     ap.add_argument("--no-strict", action="store_true",
-                    help="default cfg2 run: skip the strict-IEEE build's headline leg (`strict_fp`)")
+                    help="default cfg2 run: skip the no-contraction build's headline leg (`strict_fp`)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)

@@ -28,6 +28,8 @@
 
 #include <dlfcn.h>
 
+#include <future>
+
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -112,6 +114,37 @@ std::chrono::milliseconds collectiveTimeout(int32_t timeoutMs = 0) {
     if (s > 0) return std::chrono::milliseconds(static_cast<long long>(s * 1e3));
   }
   return std::chrono::milliseconds(300000);
+}
+
+// Runs `body` - a group of RCCL calls - so that it can be given up on.  The calls of a blocking
+// communicator may wait on the HOST for their peers (RCCL connects two ranks at their first
+// send / receive: a peer that died before that leaves ncclGroupEnd waiting for good), where no
+// stream watchdog reaches.  So they run on a helper thread; if that thread is not back within the
+// timeout, the caller aborts the communicator from here - ncclCommAbort is the one RCCL call that
+// may be made while another thread is inside the library, and it is what unblocks that thread.
+template <typename Body>
+void runAbortable(ncclComm_t &comm, int device, const char *what, Body &&body) {
+  std::promise<void> done;
+  std::future<void> fut = done.get_future();
+  std::thread helper([&] {
+    try {
+      checkHip(hipSetDevice(device), "hipSetDevice");
+      body();
+      done.set_value();
+    } catch (...) {
+      done.set_exception(std::current_exception());
+    }
+  });
+  if (fut.wait_for(collectiveTimeout()) != std::future_status::ready) {
+    const ncclComm_t c = comm;
+    comm = nullptr;
+    (void)rccl().commAbort(c);
+    helper.join();
+    throw DeviceError(PTW_ERR_HIP, std::string(what) + " did not return within the timeout (a peer that never "
+                                       "arrived?): communicator aborted");
+  }
+  helper.join();
+  fut.get();
 }
 
 // ---- loopback transport ---------------------------------------------------------------------
@@ -420,13 +453,16 @@ int ptw_comm_reduce_framebuffer(ptw_comm *comm, void *d_rgb_sum, void *d_counts,
   }
   if (!comm->comm) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
   const Rccl &api = rccl();
-  // one group: both reductions are launched together
-  checkNccl(api.groupStart(), "ncclGroupStart");
-  checkNccl(api.reduce(d_rgb_sum, d_rgb_sum, npix * 3, ncclDouble, ncclSum, root, comm->comm, stream),
-            "ncclReduce(rgb_sum)");
-  checkNccl(api.reduce(d_counts, d_counts, npix, ncclUint32, ncclSum, root, comm->comm, stream),
-            "ncclReduce(counts)");
-  checkNccl(api.groupEnd(), "ncclGroupEnd");
+  const ncclComm_t nc = comm->comm;
+  runAbortable(comm->comm, comm->device, "ncclReduce of the framebuffer", [&] {
+    // one group: both reductions are launched together
+    checkNccl(api.groupStart(), "ncclGroupStart");
+    checkNccl(api.reduce(d_rgb_sum, d_rgb_sum, npix * 3, ncclDouble, ncclSum, root, nc, stream),
+              "ncclReduce(rgb_sum)");
+    checkNccl(api.reduce(d_counts, d_counts, npix, ncclUint32, ncclSum, root, nc, stream),
+              "ncclReduce(counts)");
+    checkNccl(api.groupEnd(), "ncclGroupEnd");
+  });
   return PTW_OK;
   PTW_GUARD_END
 }
@@ -470,12 +506,15 @@ int ptw_comm_gather_rows(ptw_comm *comm, void *d_rgb_sum, void *d_counts, int32_
       }
       return PTW_OK;
     }
-    checkNccl(api->groupStart(), "ncclGroupStart");
-    if (rows) {
-      checkNccl(api->send(packRgb, rows * w * 3, ncclDouble, root, comm->comm, stream), "ncclSend(rgb)");
-      checkNccl(api->send(packCnt, rows * w, ncclUint32, root, comm->comm, stream), "ncclSend(counts)");
-    }
-    checkNccl(api->groupEnd(), "ncclGroupEnd");
+    const ncclComm_t nc = comm->comm;
+    runAbortable(comm->comm, comm->device, "ncclSend of the rows", [&] {
+      checkNccl(api->groupStart(), "ncclGroupStart");
+      if (rows) {
+        checkNccl(api->send(packRgb, rows * w * 3, ncclDouble, root, nc, stream), "ncclSend(rgb)");
+        checkNccl(api->send(packCnt, rows * w, ncclUint32, root, nc, stream), "ncclSend(counts)");
+      }
+      checkNccl(api->groupEnd(), "ncclGroupEnd");
+    });
     return PTW_OK;
   }
   // root: receive every other rank's packed rows, then scatter them into their image rows
@@ -493,14 +532,17 @@ int ptw_comm_gather_rows(ptw_comm *comm, void *d_rgb_sum, void *d_counts, int32_
       });
     }
   } else {
-    checkNccl(api->groupStart(), "ncclGroupStart");
-    for (int r = 0; r < world; ++r) {
-      if (r == root || rowsOf(r) == 0) continue;
-      char *slot = base + static_cast<size_t>(r) * (slotRgb + slotCnt);
-      checkNccl(api->recv(slot, rowsOf(r) * w * 3, ncclDouble, r, comm->comm, stream), "ncclRecv(rgb)");
-      checkNccl(api->recv(slot + slotRgb, rowsOf(r) * w, ncclUint32, r, comm->comm, stream), "ncclRecv(counts)");
-    }
-    checkNccl(api->groupEnd(), "ncclGroupEnd");
+    const ncclComm_t nc = comm->comm;
+    runAbortable(comm->comm, comm->device, "ncclRecv of the rows", [&] {
+      checkNccl(api->groupStart(), "ncclGroupStart");
+      for (int r = 0; r < world; ++r) {
+        if (r == root || rowsOf(r) == 0) continue;
+        char *slot = base + static_cast<size_t>(r) * (slotRgb + slotCnt);
+        checkNccl(api->recv(slot, rowsOf(r) * w * 3, ncclDouble, r, nc, stream), "ncclRecv(rgb)");
+        checkNccl(api->recv(slot + slotRgb, rowsOf(r) * w, ncclUint32, r, nc, stream), "ncclRecv(counts)");
+      }
+      checkNccl(api->groupEnd(), "ncclGroupEnd");
+    });
   }
   for (int r = 0; r < world; ++r) {
     if (r == root || rowsOf(r) == 0) continue;

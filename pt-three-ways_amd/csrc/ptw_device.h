@@ -132,6 +132,18 @@ __device__ __forceinline__ double reflectance(d3 n, d3 incoming, double iorFrom,
 // error < 1 ulp).  Arguments outside [-6.5, 6.5] take ocml's sincos (out of line).
 __device__ __noinline__ void sincosGeneral(double x, double *s, double *c) { sincos(x, s, c); }
 
+// A floating-point constant held in a SCALAR register pair at its point of use.  The Horner chains
+// below add a constant per step; left to itself the compiler keeps a VECTOR-register copy of every
+// addend (v_fmac wants the addend in its destination), hoists the copies out of the pixel loop, and
+// under the register pressure of the worker-wave kernels' master path spills them: round 3's
+// two-master kernels reloaded four of them from scratch memory - three serialised vmcnt(0) waits - in
+// the middle of every first-bounce scatter.  v_fma_f64 takes one scalar operand directly, and two
+// s_mov_b32 cost less than a vector register held for the whole kernel.
+__device__ __forceinline__ double sconst(double c) {
+  asm volatile("" : "+s"(c));
+  return c;
+}
+
 template <bool IN_RANGE = false> // IN_RANGE: the caller guarantees 0 <= x <= 6.5
 __device__ __forceinline__ void sinCos(double x, double &sn, double &cs) {
   // |x| <= 6.5 runs the reduction below (it is exact for negative multiples of pi/2 as well: fn is
@@ -150,13 +162,13 @@ __device__ __forceinline__ void sinCos(double x, double &sn, double &cs) {
   const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
                S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
                S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-  const double ps = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, S5), S4), S3), S2);
-  const double ks = __builtin_fma(z * r, __builtin_fma(z, ps, S1), r);
+  const double ps = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, sconst(S5)), sconst(S4)), sconst(S3)), sconst(S2));
+  const double ks = __builtin_fma(z * r, __builtin_fma(z, ps, sconst(S1)), r);
   // k_cos
   const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
                C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-  const double pc = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, C5), C4), C3), C2), C1);
+  const double pc = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, sconst(C5)), sconst(C4)), sconst(C3)), sconst(C2)), sconst(C1));
   const double hz = 0.5 * z;
   const double w = 1.0 - hz;
   const double kc = w + (((1.0 - w) - hz) + z * (z * pc));

@@ -75,6 +75,17 @@
 #ifndef PTW_SEQ_CHAIN_MASTER
 #define PTW_SEQ_CHAIN_MASTER 1
 #endif
+// Two masters per workgroup: 1 = the masters do not wait for each other - the workers poll both
+// masters' request words and answer whichever has a ray ready, no workgroup barrier on the ray path
+// (round 4); 0 = round 2's lock step, one barrier sequence for both masters (make alt
+// ALT_FLAGS=-DPTW_SEQ_DECOUPLED=0).
+#ifndef PTW_SEQ_DECOUPLED
+#define PTW_SEQ_DECOUPLED 1
+#endif
+// s_sleep argument of the polling loops of the decoupled protocol (units of 64 cycles)
+#ifndef PTW_SEQ_POLL_SLEEP
+#define PTW_SEQ_POLL_SLEEP 1
+#endif
 // default balance ratios of the worker-wave kernels (percent; seqUnitSplit)
 // (experiments build) traceSequentialGang by default when passes x 8 (or x 4) fit the CUs (0: only on PTW_SEQ_GANG=n)
 #ifndef PTW_SEQ_GANG_DEFAULT
@@ -315,15 +326,20 @@ struct alignas(16) PartialHit {
   uint32_t idxSign;
   uint32_t pad;
 };
-constexpr size_t kSeqCmdBytes = 128; // the masters' commands (56 bytes each) behind the answers
+// Behind the answers: the masters' commands (64 bytes each: ray + request number), then - decoupled
+// protocol - one word per (master, worker): the request number the worker's answer belongs to.
+constexpr size_t kSeqCmdBytes = 256;
+constexpr size_t kSeqFlagsOffset = 128; // into the command area; [MASTERS][8] words
+constexpr uint32_t kSeqDone = 0xffffffffu; // request word of a master that has no more rays
 
 // Master -> worker request of the multi-wave sequential kernel.
 constexpr uint32_t kCmdTrace = 1, kCmdExit = 2;
 constexpr uint32_t kCmdLive = 0xffffffffu; // traceSequentialMM: this master still has rays
 struct SeqCommand {
   double o[3], d[3];
-  uint32_t op;
+  uint32_t op;   // lock-step protocols: see workerLoop; decoupled: the request number (0: none yet)
   uint32_t pad;
+  uint32_t pad2[2]; // 64 bytes
 };
 
 // std::mt19937 regeneration (the "twist") + tempering + generate_canonical for all 312
@@ -434,7 +450,18 @@ struct SeqCtx {
   PartialHit *partials;  // [WAVES] cross-wave exchange (WAVES > 1)
   SeqCommand *cmd;       // master -> workers (WAVES > 1); MASTERS == 2: this master's of allCmds[2]
   SeqCommand *allCmds;   // MASTERS == 2: both masters' commands
-  unsigned tick;         // MASTERS == 2: workgroup barriers this wave has executed
+  unsigned tick;         // MASTERS == 2, lock step: workgroup barriers this wave has executed
+  // MASTERS == 2, decoupled protocol: the masters do not wait for each other.  A master publishes
+  // its ray and then the ray's request number (seq) in its command; a worker polls both masters'
+  // request words, searches whichever ray it has not answered yet, writes its answer and then, in
+  // flags[master][worker], the number of the request it belongs to; the master polls its six flags
+  // and reads the answers.  The LDS serves a wave's accesses in order, so "data first, number
+  // second" on the writing side and "number first, data second" on the reading side is all the
+  // ordering there is - no workgroup barrier on the ray path.
+  static constexpr bool kDecoupled = PTW_SEQ_DECOUPLED && MASTERS == 2;
+  uint32_t *flags;       // [MASTERS][8] in LDS
+  uint32_t seq;          // master: number of its current request (never 0, never kSeqDone)
+  int masterIndex;
   int tid;               // index among the primitive-holding lanes (workers); master: lane id
   int pos;               // next canonical double in sh->canon (wave-uniform)
   d3 envColour;          // chainHot: the environment colour, kept in vector registers
@@ -819,6 +846,69 @@ struct SeqCtx {
       if (which == 5) g21 += gap, n21++;
     }
 #endif
+    if constexpr (kDecoupled) {
+      // ---- publish: the ray, then its number (same lane, so the LDS sees them in this order) ----
+      seq = seq + 1u;
+      if (seq == kSeqDone) seq = 1u; // (numbers are only ever compared for equality)
+      if ((threadIdx.x & 63) == 0) {
+        cmd->o[0] = o.x, cmd->o[1] = o.y, cmd->o[2] = o.z;
+        cmd->d[0] = d.x, cmd->d[1] = d.y, cmd->d[2] = d.z;
+        asm volatile("" ::: "memory");
+        *reinterpret_cast<volatile uint32_t *>(&cmd->op) = seq;
+      }
+      asm volatile("" ::: "memory");
+#if PTW_PROFILE_PHASES
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      PTW_T(tDa);
+      // the search takes a thousand cycles and more: the stack entry of the level just left and the
+      // next sub-sample's first-bounce scatter
+      flushPending();
+      if (laArmed) lookAhead();
+#if PTW_PROFILE_PHASES
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      PTW_T(tDb);
+      // ---- wait for the six answers of THIS request: numbers first, answers second, one wait ----
+      const volatile uint32_t *fl = flags + masterIndex * 8;
+      PartialHit ph[WAVES];
+      for (;;) {
+        uint32_t got[WAVES];
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) got[w] = fl[w];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) ph[w] = partials[w];
+        asm volatile("" ::: "memory");
+        bool all = true;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) all = all && got[w] == seq;
+        if (uniformBool(all)) break;
+        __builtin_amdgcn_s_sleep(PTW_SEQ_POLL_SLEEP);
+      }
+      PTW_T(tDc);
+      double bt = ph[0].t;
+      uint32_t bw = ph[0].idxSign;
+#pragma unroll
+      for (int w = 1; w < WAVES; ++w) {
+        const bool take = (ph[w].t < bt) | ((ph[w].t == bt) & ((ph[w].idxSign & 0x7fffffffu) < (bw & 0x7fffffffu)));
+        bt = take ? ph[w].t : bt;
+        bw = take ? ph[w].idxSign : bw;
+      }
+      HitKey key;
+      key.t = bt;
+      key.idx = bw == kMiss ? kMiss : (bw & 0x7fffffffu);
+      key.det = (bw >> 31) ? -1.0 : 1.0; // (only its sign test is ever used)
+#if PTW_PROFILE_PHASES
+      asm volatile("" : "+v"(key.t));
+      const unsigned long long tDd = __builtin_amdgcn_s_memtime();
+      mprof[0] += tDa - tM0, mprof[2] += tDb - tDa, mprof[3] += tDc - tDb, mprof[4] += tDd - tDc;
+      prof[5] += tDd - tM0;
+      lastKind = rayKind, lastMiss = key.idx == kMiss ? 1 : 0, lastExit = __builtin_amdgcn_s_memtime();
+      rayKind = 2;
+#endif
+      return key;
+    }
     if ((threadIdx.x & 63) == 0) { // (the master wave's first lane; cmd / partials are this master's)
       cmd->o[0] = o.x, cmd->o[1] = o.y, cmd->o[2] = o.z;
       cmd->d[0] = d.x, cmd->d[1] = d.y, cmd->d[2] = d.z;
@@ -877,7 +967,48 @@ struct SeqCtx {
     unsigned long long nreq = 0;
     const unsigned long long w0 = __builtin_amdgcn_s_memtime();
 #endif
-    if (MASTERS == 2) {
+    if constexpr (kDecoupled) {
+      // Poll both masters' request words; answer whichever has a request this wave has not answered
+      // yet (both: the one it did not serve last); leave when both masters are done.  Every poll
+      // reads the two numbers first and the two rays second, in one batch.
+      uint32_t served0 = 0, served1 = 0;
+      int prefer = 0;
+      const volatile uint32_t *op0 = &allCmds[0].op, *op1 = &allCmds[1].op;
+      for (;;) {
+        const uint32_t s0 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(*op0)));
+        const uint32_t s1 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(*op1)));
+        asm volatile("" ::: "memory");
+        const SeqCommand &c0 = allCmds[0], &c1 = allCmds[1];
+        const d3 o0 = mk(c0.o[0], c0.o[1], c0.o[2]), d0 = mk(c0.d[0], c0.d[1], c0.d[2]);
+        const d3 o1 = mk(c1.o[0], c1.o[1], c1.o[2]), d1 = mk(c1.d[0], c1.d[1], c1.d[2]);
+        asm volatile("" ::: "memory");
+        const bool new0 = s0 != served0 && s0 != kSeqDone && s0 != 0u;
+        const bool new1 = s1 != served1 && s1 != kSeqDone && s1 != 0u;
+        if (!(new0 | new1)) {
+          if (s0 == kSeqDone && s1 == kSeqDone) break;
+          __builtin_amdgcn_s_sleep(PTW_SEQ_POLL_SLEEP);
+          continue;
+        }
+        const int m = (new0 & new1) ? prefer : (new1 ? 1 : 0);
+        const d3 o = m ? o1 : o0, d = m ? d1 : d0;
+        const uint32_t sm = m ? s1 : s0;
+        const HitKey found = localNearest(o, d);
+        if ((tid & 63) == 0) {
+          PartialHit ph;
+          ph.t = found.t, ph.pad = 0;
+          ph.idxSign = found.idx == kMiss ? kMiss : (found.idx | (found.det < kEpsilon ? 0x80000000u : 0u));
+          partials[m * WAVES + (tid >> 6)] = ph;
+          asm volatile("" ::: "memory");
+          *reinterpret_cast<volatile uint32_t *>(flags + m * 8 + (tid >> 6)) = sm;
+        }
+        asm volatile("" ::: "memory");
+        if (m) served1 = sm; else served0 = sm;
+        prefer = m ^ 1;
+#if PTW_PROFILE_PHASES
+        nreq++;
+#endif
+      }
+    } else if (MASTERS == 2) {
       // Barrier n is followed by the search of master (n & 1)'s ray, which that master published
       // before it.  A command's `op` holds the barrier index from which its master has no more
       // rays (kCmdLive while it has): a value that reads the same whenever it is looked at, so all
@@ -931,6 +1062,11 @@ struct SeqCtx {
   }
   __device__ __forceinline__ void stopWorkers() {
     if (WAVES == 1) return;
+    if constexpr (kDecoupled) {
+      // (every request of this master has been answered: nothing of it is pending anywhere)
+      if ((threadIdx.x & 63) == 0) *reinterpret_cast<volatile uint32_t *>(&cmd->op) = kSeqDone;
+      return;
+    }
     if (MASTERS == 2) {
       // no more rays from this master as of its next barrier; keep the cadence until the other
       // one is done too (see workerLoop)
@@ -1341,6 +1477,7 @@ __host__ __device__ inline size_t seqLdsBytes(int waves, int maxDepth, bool ldsT
                                               uint32_t nmat, uint32_t nsph, int masters = 1) {
   size_t n = masters * sizeof(SeqShared);
   n += static_cast<size_t>(waves) * (maxDepth > 0 ? maxDepth : 1) * sizeof(Level);
+  n = (n + 15) & ~static_cast<size_t>(15); // the answers: 16-byte aligned (ds_read_b128)
   n += masters * static_cast<size_t>(waves) * sizeof(PartialHit) + kSeqCmdBytes;
   n = (n + 63) & ~static_cast<size_t>(63);
   if (ldsTables) {
@@ -1365,9 +1502,14 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
   const int master = MASTERS == 1 ? 0 : (threadIdx.x >> 6 < MASTERS ? threadIdx.x >> 6 : 0);
   SeqShared &sh = reinterpret_cast<SeqShared *>(ldsRaw)[master];
   Level *stacks = reinterpret_cast<Level *>(ldsRaw + MASTERS * sizeof(SeqShared));
-  PartialHit *partials = reinterpret_cast<PartialHit *>(stacks + WAVES * depthSlots);
-  size_t off = MASTERS * sizeof(SeqShared) + static_cast<size_t>(WAVES) * depthSlots * sizeof(Level) +
-               MASTERS * static_cast<size_t>(WAVES) * sizeof(PartialHit) + kSeqCmdBytes;
+  PartialHit *partials = reinterpret_cast<PartialHit *>(
+      ldsRaw + ((MASTERS * sizeof(SeqShared) + static_cast<size_t>(WAVES) * (p.maxDepth > 0 ? p.maxDepth : 1) * sizeof(Level) + 15) &
+                ~static_cast<size_t>(15)));
+  // (the answers are read with ds_read_b128: their offset is rounded up to 16 bytes - with seven
+  // worker waves and an odd maxDepth the stacks end on 8 mod 16)
+  const size_t partialsOff = (MASTERS * sizeof(SeqShared) + static_cast<size_t>(WAVES) * depthSlots * sizeof(Level) + 15) &
+                             ~static_cast<size_t>(15);
+  size_t off = partialsOff + MASTERS * static_cast<size_t>(WAVES) * sizeof(PartialHit) + kSeqCmdBytes;
   off = (off + 63) & ~static_cast<size_t>(63);
 
   const int pass = blockIdx.x * MASTERS + master;
@@ -1409,6 +1551,11 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
   ctx.allCmds = reinterpret_cast<SeqCommand *>(partials + MASTERS * WAVES);
   ctx.partials = isWorker ? partials : partials + master * WAVES;
   ctx.cmd = ctx.allCmds + master;
+  ctx.flags = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(ctx.allCmds) + kSeqFlagsOffset);
+  ctx.seq = 0;
+  ctx.masterIndex = master;
+  static_assert(MASTERS * sizeof(SeqCommand) <= kSeqFlagsOffset && kSeqFlagsOffset + MASTERS * 8 * sizeof(uint32_t) <= kSeqCmdBytes &&
+                    WAVES <= 8, "commands and answer numbers fit");
   ctx.tick = 0;
   ctx.laArmed = false;
   ctx.laPos = -1;
@@ -1458,7 +1605,10 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
         waveSync();
         if (ctx.pos < kMtDoubles) ctx.rebuildCanonWave();
       }
-      if (lane == 0) ctx.cmd->op = hasPass ? kCmdLive : 0u;
+      // lock step: "live" / "no rays as of barrier 0"; decoupled: no request yet / done
+      if (lane == 0) ctx.cmd->op = SeqCtx<SLOTS, WAVES, LDS_TABLES, REG, false, MASTERS>::kDecoupled
+                                       ? (hasPass ? 0u : kSeqDone) : (hasPass ? kCmdLive : 0u);
+      if (lane < 8) ctx.flags[master * 8 + lane] = 0u;
     }
     __syncthreads();
   }
@@ -1468,8 +1618,8 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
   } else if (!hasPass) {
     ctx.stopWorkers();
   } else {
-  if (MASTERS == 2 && master == 1) { // the second master runs one barrier behind the first
-    ldsBarrier();
+  if (MASTERS == 2 && !SeqCtx<SLOTS, WAVES, LDS_TABLES, REG, false, MASTERS>::kDecoupled && master == 1) {
+    ldsBarrier(); // lock step: the second master runs one barrier behind the first
     ctx.tick = 1;
   }
   // (raising the master waves' priority over the worker that shares their SIMD - s_setprio 1..3 -

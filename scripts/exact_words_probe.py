@@ -7,7 +7,7 @@ the strict oracle's counts for that pass: a build that differs from the shipped 
 those three samples and equals the oracle there takes every decision of the frame as the reference
 does.
 
-    python scripts/exact_words_probe.py libptw_hip_exact.so [libptw_hip.so]
+    python scripts/exact_words_probe.py libptw_hip_strict.so [libptw_hip.so]
 """
 import os
 import subprocess
@@ -43,7 +43,7 @@ def render(lib, out):
 
 def main():
     import numpy as np
-    a = sys.argv[1] if len(sys.argv) > 1 else "libptw_hip_exact.so"
+    a = sys.argv[1] if len(sys.argv) > 1 else "libptw_hip_strict.so"
     b = sys.argv[2] if len(sys.argv) > 2 else "libptw_hip.so"
     fa, fb = "/dev/shm/ptw_words_a.npy", "/dev/shm/ptw_words_b.npy"
     t = time.time()

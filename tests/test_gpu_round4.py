@@ -179,9 +179,13 @@ if rank == 1:
 rgb = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
 cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
-comm.gather_rows(rgb.data_ptr(), cnt.data_ptr(), w, h, 0, stream)   # enqueued: waits for rank 1's rows
 t0 = time.time()
 try:
+    # the receive of rank 1's rows: RCCL connects the two ranks here, on the host - with the peer gone
+    # either this call is given up on (PTW_COLLECTIVE_TIMEOUT_S) or, if the connection was made in
+    # time, the enqueued receive never completes and the stream watchdog ends it
+    comm.gather_rows(rgb.data_ptr(), cnt.data_ptr(), w, h, 0, stream)
+    print("ENQUEUED after %.1f s" % (time.time() - t0), flush=True)
     comm.wait(stream, 10000)
     print("NO_ERROR")
 except pkg.PtwError as e:
@@ -192,15 +196,18 @@ os._exit(0)              # (no teardown of a communicator whose peer is gone)
 
 def test_rccl_peer_that_exits_is_an_error_not_a_hang(tmp_path):
     """The same on the RCCL transport, two processes on one GPU (NCCL_HOSTID, socket transport): rank 1
-    exits without sending; rank 0's gather is enqueued and ptw_comm_wait - polling
-    ncclCommGetAsyncError and a deadline around the stream - returns PTW_ERR_HIP."""
+    exits without sending.  Rank 0's gather either blocks on the HOST (RCCL connects two ranks at their
+    first send / receive) - the call runs on a helper thread and the communicator is aborted from the
+    calling thread after the timeout - or is enqueued and never completes - ptw_comm_wait, polling
+    ncclCommGetAsyncError and a deadline around the stream, aborts it.  Either way: PTW_ERR_HIP."""
     script = tmp_path / "peer.py"
     script.write_text(PEER_EXIT_SCRIPT.format(root=str(ROOT)))
     uid_file = str(tmp_path / "uid.bin")
     procs = []
     for r in range(2):
         env = dict(os.environ, NCCL_HOSTID=f"ptw-test-host-{r}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1",
-                   NCCL_P2P_DISABLE="1", NCCL_SHM_DISABLE="1", NCCL_DEBUG="WARN", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   NCCL_P2P_DISABLE="1", NCCL_SHM_DISABLE="1", NCCL_DEBUG="WARN", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   PTW_COLLECTIVE_TIMEOUT_S="10")
         procs.append(subprocess.Popen([sys.executable, str(script), str(r), uid_file], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []

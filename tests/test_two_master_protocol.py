@@ -1,6 +1,10 @@
-"""CPU model of the barrier protocol of the two-master worker kernel
+"""CPU models of the two protocols of the two-master worker kernel
 (pt-three-ways_amd/csrc/ptw_kernels.hip: SeqCtx<..., MASTERS = 2>::intersect / workerLoop /
-stopWorkers and the role set-up in traceSequential).
+stopWorkers and the role set-up in traceSequential): the DECOUPLED protocol of round 4 (the default:
+request numbers and answer numbers in LDS, no workgroup barrier on the ray path - second half of this
+file) and round 2's LOCK STEP (-DPTW_SEQ_DECOUPLED=0, kept for A/B runs - first half).
+
+Lock step:
 
 Every wave of the workgroup is a generator that yields at each workgroup barrier; the scheduler
 releases a barrier only when ALL live waves have arrived (what s_barrier does), so a protocol in
@@ -106,7 +110,7 @@ def run(rays0, rays1, has1=True, order_seed=None):
     return g, barriers
 
 
-def test_two_master_protocol_all_ray_counts():
+def test_lock_step_protocol_all_ray_counts():
     for rays0, rays1, has1 in itertools.product(range(0, 7), range(0, 7), (True, False)):
         if not has1 and rays1:
             continue
@@ -174,3 +178,121 @@ def test_slot_major_assignment_gives_the_empty_slots_to_the_waves_beside_a_maste
             # the waves beside a master never hold more than any other wave
             load = {w: sum(1 for hw, _ in holder.values() if hw == w) for w in ranks}
             assert max(load[w] for w in shared) <= min(load[w] for w in ranks if w not in shared)
+
+
+# ---- the decoupled protocol (PTW_SEQ_DECOUPLED = 1) ------------------------------------------------
+# Every wave is a generator that yields between any two of its LDS accesses whose order matters; the
+# scheduler runs ONE step of ONE wave at a time, in an order a seeded generator picks - every
+# interleaving the hardware could produce of in-order LDS streams is a possible schedule here.  The
+# rules the kernel relies on: a writer stores its data BEFORE the number that announces it; a reader
+# loads the number BEFORE the data.
+DONE = 0xFFFFFFFF
+
+
+class Lds:
+    def __init__(self):
+        self.op = [0, 0]                                     # SeqCommand::op: the request number
+        self.ray = [None, None]
+        self.answer = [[None] * WORKERS, [None] * WORKERS]   # PartialHit
+        self.flag = [[0] * WORKERS, [0] * WORKERS]           # number of the request the answer belongs to
+        self.searched = []                                   # (worker, master, ray)
+        self.reads = []                                      # (master, ray, answers)
+        self.done_at = {}                                    # wave -> scheduler step at which it left
+
+
+def d_master(g, m, rays, has_pass):
+    if not has_pass:
+        g.op[m] = DONE          # (set in the prologue, before the workgroup's only __syncthreads)
+        return
+    seq = 0
+    for r in range(rays):
+        seq += 1
+        g.ray[m] = (m, r)       # the ray ...
+        yield
+        g.op[m] = seq           # ... then its number
+        yield                   # (flushPending / lookAhead: the master's own work)
+        while True:
+            got = list(g.flag[m])          # numbers first
+            yield
+            answers = list(g.answer[m])    # answers second
+            if all(f == seq for f in got):
+                break
+            yield               # s_sleep
+        g.reads.append((m, (m, r), answers))
+    g.op[m] = DONE
+
+
+def d_worker(g, w):
+    served = [0, 0]
+    prefer = 0
+    while True:
+        s = [g.op[0], g.op[1]]             # numbers first
+        yield
+        rays = [g.ray[0], g.ray[1]]        # rays second
+        new = [s[i] != served[i] and s[i] not in (0, DONE) for i in (0, 1)]
+        if not (new[0] or new[1]):
+            if s[0] == DONE and s[1] == DONE:
+                return
+            yield                          # s_sleep
+            continue
+        m = prefer if (new[0] and new[1]) else (1 if new[1] else 0)
+        yield                              # the search
+        g.searched.append((w, m, rays[m]))
+        g.answer[m][w] = (rays[m], w)      # the answer ...
+        yield
+        g.flag[m][w] = s[m]                # ... then its number
+        served[m] = s[m]
+        prefer = m ^ 1
+
+
+def d_run(rays0, rays1, has1, seed, starve=None):
+    """`starve`: a wave the scheduler does not run while any other wave can make progress towards its
+    own end (None: fair).  Starving master 1 shows that master 0 does not wait for it."""
+    rnd = random.Random(seed)
+    g = Lds()
+    waves = {"m0": d_master(g, 0, rays0, True), "m1": d_master(g, 1, rays1, has1)}
+    waves.update({f"w{w}": d_worker(g, w) for w in range(WORKERS)})
+    live = list(waves)
+    for step in range(400 * (rays0 + rays1 + 2)):
+        if not live:
+            break
+        pool = [n for n in live if n != starve] or live
+        if starve == "m1" and "m0" not in live:
+            pool = live                    # master 0 is through: let the starved one run
+        name = rnd.choice(pool)
+        try:
+            next(waves[name])
+        except StopIteration:
+            live.remove(name)
+            g.done_at[name] = step
+    assert not live, f"deadlock / livelock: {live} still running"
+    return g
+
+
+def test_decoupled_protocol_all_ray_counts_and_schedules():
+    for rays0, rays1, has1 in itertools.product(range(0, 6), range(0, 6), (True, False)):
+        if not has1 and rays1:
+            continue
+        expect = [(0, r) for r in range(rays0)] + ([(1, r) for r in range(rays1)] if has1 else [])
+        for seed in range(12):
+            g = d_run(rays0, rays1, has1, seed)
+            # every published ray searched by every worker exactly once ...
+            assert sorted(g.searched) == sorted((w, ray[0], ray) for ray in expect for w in range(WORKERS))
+            # ... and read by ITS master, in order, with the six answers of THAT ray
+            assert [ray for m, ray, _ in g.reads if m == 0] == [(0, r) for r in range(rays0)]
+            assert [ray for m, ray, _ in g.reads if m == 1] == ([(1, r) for r in range(rays1)] if has1 else [])
+            for m, ray, answers in g.reads:
+                assert answers == [(ray, w) for w in range(WORKERS)]
+            # the workers leave only after both masters are done
+            last_master = max(g.done_at["m0"], g.done_at["m1"])
+            assert all(g.done_at[f"w{w}"] > last_master for w in range(WORKERS))
+
+
+def test_decoupled_masters_do_not_wait_for_each_other():
+    """The point of the protocol: with master 1 not scheduled at all, master 0 traces every one of its
+    rays (in lock step it would sit at the first barrier master 1 does not reach)."""
+    for seed in range(8):
+        g = d_run(5, 4, True, seed, starve="m1")
+        assert g.done_at["m0"] < g.done_at["m1"]
+        first_m1_read = min(i for i, (m, _, _) in enumerate(g.reads) if m == 1)
+        assert [ray for m, ray, _ in g.reads[:first_m1_read]] == [(0, r) for r in range(5)]
