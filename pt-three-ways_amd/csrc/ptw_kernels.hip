@@ -86,6 +86,11 @@
 #ifndef PTW_SEQ_POLL_SLEEP
 #define PTW_SEQ_POLL_SLEEP 1
 #endif
+// 1: whoever writes a request or an answer number then executes s_wakeup, which ends the s_sleep of
+// every wave of the workgroup that waits in a polling loop
+#ifndef PTW_SEQ_WAKEUP
+#define PTW_SEQ_WAKEUP 0
+#endif
 // default balance ratios of the worker-wave kernels (percent; seqUnitSplit)
 // (experiments build) traceSequentialGang by default when passes x 8 (or x 4) fit the CUs (0: only on PTW_SEQ_GANG=n)
 #ifndef PTW_SEQ_GANG_DEFAULT
@@ -382,6 +387,14 @@ struct SeqTables {
 
 // Layout of the per-lane shading record of the REG path (doubles).
 constexpr int kRecEmission = 0, kRecDiffuse = 3, kRecDoubles = 6;
+
+// Decoupled protocol: after the number that announces a request / an answer has been written, wake
+// the waves that sleep in their polling loops (the write has to have reached the LDS first).
+__device__ __forceinline__ void seqSignal() {
+#if PTW_SEQ_WAKEUP
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory");
+#endif
+}
 
 template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false, bool SPEC = false, int MASTERS = 1>
 struct SeqCtx {
@@ -857,6 +870,7 @@ struct SeqCtx {
         *reinterpret_cast<volatile uint32_t *>(&cmd->op) = seq;
       }
       asm volatile("" ::: "memory");
+      seqSignal();
 #if PTW_PROFILE_PHASES
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -870,12 +884,12 @@ struct SeqCtx {
 #endif
       PTW_T(tDb);
       // ---- wait for the six answers of THIS request: numbers first, answers second, one wait ----
-      const volatile uint32_t *fl = flags + masterIndex * 8;
+      typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+      const volatile U4 *fl = reinterpret_cast<const volatile U4 *>(flags + masterIndex * 8);
       PartialHit ph[WAVES];
       for (;;) {
-        uint32_t got[WAVES];
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) got[w] = fl[w];
+        const U4 lo = fl[0], hi = fl[1]; // the eight numbers of this master: two ds_read_b128
+        const uint32_t got[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) ph[w] = partials[w];
@@ -1002,6 +1016,7 @@ struct SeqCtx {
           *reinterpret_cast<volatile uint32_t *>(flags + m * 8 + (tid >> 6)) = sm;
         }
         asm volatile("" ::: "memory");
+        seqSignal();
         if (m) served1 = sm; else served0 = sm;
         prefer = m ^ 1;
 #if PTW_PROFILE_PHASES
@@ -1065,6 +1080,7 @@ struct SeqCtx {
     if constexpr (kDecoupled) {
       // (every request of this master has been answered: nothing of it is pending anywhere)
       if ((threadIdx.x & 63) == 0) *reinterpret_cast<volatile uint32_t *>(&cmd->op) = kSeqDone;
+      seqSignal();
       return;
     }
     if (MASTERS == 2) {
