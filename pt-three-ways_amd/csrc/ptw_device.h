@@ -139,8 +139,13 @@ __device__ __noinline__ void sincosGeneral(double x, double *s, double *c) { sin
 // two-master kernels reloaded four of them from scratch memory - three serialised vmcnt(0) waits - in
 // the middle of every first-bounce scatter.  v_fma_f64 takes one scalar operand directly, and two
 // s_mov_b32 cost less than a vector register held for the whole kernel.
+#ifndef PTW_SCONST
+#define PTW_SCONST 1 // (0: A/B switch - the compiler's own placement of the constants)
+#endif
 __device__ __forceinline__ double sconst(double c) {
+#if PTW_SCONST
   asm volatile("" : "+s"(c));
+#endif
   return c;
 }
 

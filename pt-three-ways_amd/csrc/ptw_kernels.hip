@@ -75,12 +75,13 @@
 #ifndef PTW_SEQ_CHAIN_MASTER
 #define PTW_SEQ_CHAIN_MASTER 1
 #endif
-// Two masters per workgroup: 1 = the masters do not wait for each other - the workers poll both
-// masters' request words and answer whichever has a ray ready, no workgroup barrier on the ray path
-// (round 4); 0 = round 2's lock step, one barrier sequence for both masters (make alt
-// ALT_FLAGS=-DPTW_SEQ_DECOUPLED=0).
+// Two masters per workgroup: 0 = round 2's lock step, one barrier sequence for both masters (the
+// shipped form); 1 = the masters do not wait for each other - the workers poll both masters' request
+// words and answer whichever has a ray ready, no workgroup barrier on the ray path (round 4: built,
+// bit-identical, measured 3-15 % SLOWER - an LDS flag costs a polling round trip where s_barrier costs
+// 55 cycles; DESIGN.md 3.1.  In the experiments build, or make alt ALT_FLAGS=-DPTW_SEQ_DECOUPLED=1).
 #ifndef PTW_SEQ_DECOUPLED
-#define PTW_SEQ_DECOUPLED 1
+#define PTW_SEQ_DECOUPLED PTW_EXPERIMENTS // (measured slower than the lock step: DESIGN.md 3.1; experiments build only)
 #endif
 // s_sleep argument of the polling loops of the decoupled protocol (units of 64 cycles)
 #ifndef PTW_SEQ_POLL_SLEEP

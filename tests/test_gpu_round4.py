@@ -223,3 +223,61 @@ def test_rccl_peer_that_exits_is_an_error_not_a_hang(tmp_path):
     if "RCCL_REFUSED" in text or "COMM_UP 0" not in text:
         pytest.skip("RCCL refused two ranks on one GPU: " + text[-600:])
     assert "WATCHDOG_OK status 3" in text and "NO_ERROR" not in text, text
+
+
+# ---- the decoupled two-master protocol (experiments build only: measured slower) -----
+DECOUPLED_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+import numpy as np
+import torch
+import oracle_binding as ob
+import test_gpu_round3 as r3
+pkg = ob.pkg
+os.environ["PTW_SEQ_MM"] = "1"
+ran = set()
+for ntri, tables, kernel in r3.TWO_MASTER_CASES:
+    for spp, budget_kb in ((3, None), (4, 1)):
+        os.environ.pop("PTW_SEQ_LDS_TABLES", None); os.environ.pop("PTW_STAGE_BUDGET_KB", None)
+        if tables == "global" and ntri < 1400:
+            os.environ["PTW_SEQ_LDS_TABLES"] = "0"
+        if budget_kb:
+            os.environ["PTW_STAGE_BUDGET_KB"] = str(budget_kb)
+        w, h = (12, 10) if budget_kb else (4, 3)
+        scene, cam = r3._soup(pkg, ntri, 2, seed=31 * ntri + spp, w=w, h=h)
+        params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=5)
+        ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(scene.view(), cam, params, threads=4)
+        rgb, cnt, words, variant, launches = r3._render_with_stats(pkg, scene, cam, params)
+        assert variant == kernel, variant
+        assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words), (ntri, tables, spp)
+        assert r3.rel_err(rgb, ref_rgb) < 1e-12
+        ran.add(variant)
+# the BASELINE scenes, natural dispatch (more passes than CUs)
+del os.environ["PTW_SEQ_MM"]; os.environ.pop("PTW_SEQ_LDS_TABLES", None); os.environ.pop("PTW_STAGE_BUDGET_KB", None)
+cus = torch.cuda.get_device_properties(0).multi_processor_count
+for name, edge in (("suzanne", 6), ("ce", 3)):
+    scene = pkg.Scene(); cam = scene.build_named(name, edge, edge)
+    params = pkg.default_params(width=edge, height=edge, samples_per_pixel=cus + 1, seed=2)
+    ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(scene.view(), cam, params, threads=8)
+    rgb, cnt, words, variant, _ = r3._render_with_stats(pkg, scene, cam, params)
+    assert variant.endswith(",2 masters>"), variant
+    assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words), name
+    assert r3.rel_err(rgb, ref_rgb) < 1e-12
+print("DECOUPLED_OK", len(ran))
+"""
+
+
+def test_decoupled_two_master_protocol_matches_oracle(pkg, tmp_path):
+    """masters that do not wait for each other - the workers poll both masters'
+    request numbers in LDS and answer whichever has a ray, no workgroup barrier on the ray path.  Built,
+    bit-identical to the oracle on every two-master instantiation (odd / even passes, parked streams) and
+    on suzanne / ce through the natural dispatch - and measured 3-15 % slower than the lock step (DESIGN.md
+    3.1), so it lives in the experiments build (-DPTW_SEQ_DECOUPLED=1) and runs here in a child process."""
+    lib = pkg.LIB_PATH.parent / "experiments" / "libptw_hip.so"
+    if not lib.exists():
+        pytest.skip("experiments library not built (make -C pt-three-ways_amd experiments)")
+    script = tmp_path / "decoupled.py"
+    script.write_text(DECOUPLED_SCRIPT.format(root=str(ROOT)))
+    proc = subprocess.run([sys.executable, str(script)], env=dict(os.environ, PTW_LIB_PATH=str(lib)),
+                          capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0 and "DECOUPLED_OK 11" in proc.stdout, proc.stdout[-1500:] + proc.stderr[-3000:]
