@@ -134,22 +134,23 @@ __device__ __noinline__ void sincosGeneral(double x, double *s, double *c) { sin
 
 // A floating-point constant held in a SCALAR register pair at its point of use.  The Horner chains
 // below add a constant per step; left to itself the compiler keeps a VECTOR-register copy of every
-// addend (v_fmac wants the addend in its destination), hoists the copies out of the pixel loop, and
-// under the register pressure of the worker-wave kernels' master path spills them: round 3's
-// two-master kernels reloaded four of them from scratch memory - three serialised vmcnt(0) waits - in
-// the middle of every first-bounce scatter.  v_fma_f64 takes one scalar operand directly, and two
-// s_mov_b32 cost less than a vector register held for the whole kernel.
-#ifndef PTW_SCONST
-#define PTW_SCONST 1 // (0: A/B switch - the compiler's own placement of the constants)
-#endif
+// addend (v_fmac wants the addend in its destination) and hoists the copies out of the pixel loop.
+// Where registers are short - the master path of the two-master worker-wave kernels, the PERPIXEL
+// kernels at four waves per SIMD - it then spills them: round 3's two-master kernels reloaded four of
+// them from scratch memory, three serialised vmcnt(0) waits, in the middle of every first-bounce
+// scatter.  v_fma_f64 takes one scalar operand directly: with the constants in scalar registers
+// those kernels spill nothing (28 -> 0 and 10 -> 0 registers).  It is NOT free where a wave has its
+// SIMD to itself: two s_mov_b32 per constant are two issue slots on the serial path, and the
+// single-wave-per-SIMD kernels (traceSequentialSpec: 7.60 against 7.76 Msamples/s on the headline
+// scene, same box) never spilled - so the choice is a template parameter (SC), per kernel family.
+// Same operations in the same order either way: same bits.
+template <bool SC>
 __device__ __forceinline__ double sconst(double c) {
-#if PTW_SCONST
-  asm volatile("" : "+s"(c));
-#endif
+  if constexpr (SC) asm volatile("" : "+s"(c));
   return c;
 }
 
-template <bool IN_RANGE = false> // IN_RANGE: the caller guarantees 0 <= x <= 6.5
+template <bool IN_RANGE = false, bool SC = false> // IN_RANGE: the caller guarantees 0 <= x <= 6.5
 __device__ __forceinline__ void sinCos(double x, double &sn, double &cs) {
   // |x| <= 6.5 runs the reduction below (it is exact for negative multiples of pi/2 as well: fn is
   // then negative and every product fn * c_i stays exact); cone angles are in [-pi, pi]
@@ -167,13 +168,13 @@ __device__ __forceinline__ void sinCos(double x, double &sn, double &cs) {
   const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
                S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
                S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-  const double ps = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, sconst(S5)), sconst(S4)), sconst(S3)), sconst(S2));
-  const double ks = __builtin_fma(z * r, __builtin_fma(z, ps, sconst(S1)), r);
+  const double ps = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, sconst<SC>(S5)), sconst<SC>(S4)), sconst<SC>(S3)), sconst<SC>(S2));
+  const double ks = __builtin_fma(z * r, __builtin_fma(z, ps, sconst<SC>(S1)), r);
   // k_cos
   const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
                C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-  const double pc = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, sconst(C5)), sconst(C4)), sconst(C3)), sconst(C2)), sconst(C1));
+  const double pc = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, sconst<SC>(C5)), sconst<SC>(C4)), sconst<SC>(C3)), sconst<SC>(C2)), sconst<SC>(C1));
   const double hz = 0.5 * z;
   const double w = 1.0 - hz;
   const double kc = w + (((1.0 - w) - hz) + z * (z * pc));
@@ -196,11 +197,12 @@ __device__ __forceinline__ d3 normalisedNearUnit(d3 a) {
 }
 
 // hemisphereSample, src/math/Samples.cpp:21-30
+template <bool SC = false>
 __device__ __forceinline__ d3 hemisphereSample(const Basis &basis, double u, double v) {
   const double theta = (2 * kPi) * u;
   const double radius = sqrtPos(v);
   double s, c;
-  sinCos<true>(theta, s, c); // u is a (stratified) canonical draw: theta in [0, 2 pi)
+  sinCos<true, SC>(theta, s, c); // u is a (stratified) canonical draw: theta in [0, 2 pi)
   // (c r, s r, sqrt(1 - v)) has squared length v + (1 - v) and the basis is orthonormal, so the
   // transformed vector is unit length up to a few ulp
   return normalisedNearUnit(transform(basis, mk(c * radius, s * radius, sqrtPos(1 - v))));
@@ -211,10 +213,10 @@ __device__ __noinline__ d3 coneSample(d3 direction, double coneTheta, double u, 
   if (coneTheta < kEpsilon) return direction;
   coneTheta = coneTheta * (1.0 - (2.0 * acos(u) / kPi));
   double radius, zScale;
-  sinCos(coneTheta, radius, zScale);
+  sinCos<false, true>(coneTheta, radius, zScale);
   const double randomTheta = v * 2 * kPi;
   double s, c;
-  sinCos<true>(randomTheta, s, c); // v is a (stratified) canonical draw
+  sinCos<true, true>(randomTheta, s, c); // v is a (stratified) canonical draw
   const Basis basis = basisFromZ(direction);
   return normalised(transform(basis, mk(c * radius, s * radius, zScale)));
 }

@@ -184,7 +184,7 @@ __device__ __forceinline__ bool scatter(CTX &ctx, const Surface &s, d3 dirIn, do
     dirOut = coneSample(reflect(s.normal, dirIn), s.coneAngle, u, v);
     return true;
   }
-  dirOut = hemisphereSample(s.basis, u, v); // Scene.cpp:169-175
+  dirOut = hemisphereSample<CTX::kScalarConsts>(s.basis, u, v); // Scene.cpp:169-175
   return false;
 }
 
@@ -421,6 +421,9 @@ struct SeqCtx {
   // the master is looking at right now: it is evaluated in that idle time, and taken if the
   // position still matches when the next sub-sample starts (lookAhead / takeLookAhead).
   static constexpr bool kLookAhead = WAVES > 1;
+  // sincos constants in scalar registers (ptw_device.h, sconst()): the two-master kernels, whose
+  // master path is short of vector registers
+  static constexpr bool kScalarConsts = MASTERS == 2;
   // two masters per workgroup: radiance0 and the chain use chainMaster / chainMasterFrom
   static constexpr bool kMasterChain = PTW_SEQ_CHAIN_MASTER && WAVES > 1 && MASTERS == 2;
   Surface laSurf;  // look-ahead inputs: the first-bounce surface, the incoming direction (set once per
@@ -1666,7 +1669,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
       r1 = ctx.draw();
     }
     d3 o, d;
-    cameraRay(p.cam, px, py, r0, r1, r2, r3, o, d);
+    cameraRay<MASTERS == 2>(p.cam, px, py, r0, r1, r2, r3, o, d);
     ctx.acc(10, tC0, d.x);
     const d3 L = radiance0(ctx, p, triShade, spheres, o, d);
     if (lane == 0) {
@@ -2157,6 +2160,7 @@ template <bool BVH>
 struct PixCtxT {
   static constexpr bool kLookAhead = false; // (radiance0: a lane never waits for anybody here)
   static constexpr bool kMasterChain = false;
+  static constexpr bool kScalarConsts = true; // (four waves per SIMD at 128 registers: ptw_device.h, sconst())
   const TraceParams *p;
   const double *triGeom;
   const TriShade *triShade;
@@ -2447,7 +2451,7 @@ __device__ __forceinline__ void perPixelSample(const TraceParams &p, const Trace
     r3 = ctx.draw();
   }
   d3 o, d;
-  cameraRay(p.cam, px, py, r0, r1, r2, r3, o, d);
+  cameraRay<true>(p.cam, px, py, r0, r1, r2, r3, o, d);
 #if PTW_PIX_REBUILD
   const d3 L = radiance0Pix(ctx, p, b.triShade, b.spheres, o, d);
 #else
@@ -2572,7 +2576,7 @@ __global__ __launch_bounds__(kPix2Block) __attribute__((amdgpu_waves_per_eu(W, W
       r2 = draw();
       r3 = draw();
     }
-    cameraRay(p.cam, px, py, r0, r1, r2, r3, o, d);
+    cameraRay<true>(p.cam, px, py, r0, r1, r2, r3, o, d);
     depth = 0;
     stRng(rng);
     stW(kWCount, nwords), stW(kWPass, pass), stW(kWPix, pixIdx);
@@ -2776,7 +2780,7 @@ __global__ __launch_bounds__(kPix2Block) __attribute__((amdgpu_waves_per_eu(W, W
           nd = coneSample(reflect(normal, sDin), coneAngle, u, v);
           refl = true;
         } else {
-          nd = hemisphereSample(basis, u, v);
+          nd = hemisphereSample<true>(basis, u, v);
           refl = false;
         }
         // push: one word per level (combined primitive index + lobe flag)

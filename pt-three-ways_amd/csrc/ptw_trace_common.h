@@ -114,6 +114,7 @@ __device__ __forceinline__ void testSphere(d3 o, d3 d, d3 centre, double radiusS
 
 // Camera::rayFromUnit / randomRay, src/math/Camera.h:20-37,54-60.  r0..r3 are canonical
 // draws in stream order (r2, r3 unused for a pinhole camera).
+template <bool SC = false> // (SC: polynomial constants in scalar registers, ptw_device.h sconst())
 __device__ __forceinline__ void cameraRay(const ptw_camera &c, int px, int py, double r0,
                                           double r1, double r2, double r3, d3 &o, d3 &d) {
   const double x0 = (px + r0) * c.reciprocal_width;
@@ -133,7 +134,7 @@ __device__ __forceinline__ void cameraRay(const ptw_camera &c, int px, int py, d
   const double angle = r2 * (2 * kPi - 0) + 0;      // uniform_real_distribution(0, 2*pi)
   const double radius = r3 * (c.aperture_radius - 0) + 0;
   double sn, cs;
-  sinCos<true>(angle, sn, cs); // r2 in [0, 1)
+  sinCos<true, SC>(angle, sn, cs); // r2 in [0, 1)
   const d3 origin = (centre + (ax * cs) * radius) + (ay * sn) * radius;
   o = origin;
   d = normalised(focalPoint - origin); // Ray::fromTwoPoints, Ray.h:12-15
