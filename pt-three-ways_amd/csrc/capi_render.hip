@@ -363,18 +363,12 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   if (minBands > 1) bandPix = std::min<uint64_t>(bandPix, (pixTotal + minBands - 1) / minBands);
   bandPix = std::max<uint64_t>(bandPix, 64);
   bandPix = std::min<uint64_t>(bandPix, pixTotal);
-  // The many-candidate sequential kernels (traceSequentialGang; the experiments build's wide kernels)
-  // pick their speculation candidates per band from the statistics of
+  // The many-candidate sequential kernel (traceSequentialGang, experiments build) picks its
+  // speculation candidates per band from the statistics of
   // the band before: give it a short first band to measure on and at least eight bands, so that
   // the set follows the image from top to bottom.
   TraceParams shape = t; // (what the dispatcher looks at: scene size, depth, pass count)
   bool adaptive = sequential && pixTotal >= 16384 && seqGangGroups(shape) > 0;
-#if PTW_EXPERIMENTS
-  const char *wideEnv = std::getenv("PTW_SEQ_WIDE");
-  const char *spec8Env = std::getenv("PTW_SEQ_SPEC8");
-  adaptive = adaptive || (sequential && pixTotal >= 16384 && ctx.ntri <= 64 &&
-                          ((wideEnv && wideEnv[0] == '1' && wideKernelApplies(t)) || (spec8Env && spec8Env[0] == '1')));
-#endif
   if (adaptive) bandPix = std::min<uint64_t>(bandPix, (pixTotal + 7) / 8);
   // equal bands (the last one is not a sliver)
   const uint64_t nBands = (pixTotal + bandPix - 1) / bandPix;

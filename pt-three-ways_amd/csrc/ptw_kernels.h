@@ -95,11 +95,9 @@ struct TraceBuffers {
 // `variant` (may be null) receives the name of the kernel variant that was launched.
 hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hipStream_t stream,
                                  const char **variant = nullptr);
-// traceSequentialWide (ptw_wide.hip): the SEQUENTIAL policy for small scenes with many speculative
-// candidates per round.  Needs b.countHist (zeroed once) and b.wideCands (wideCandidateBytes()):
-// before the trace kernel a one-lane kernel builds the candidate set from the histogram of
-// per-sub-sample draw counts the previous launch left in countHist.
-bool wideKernelApplies(const TraceParams &p);
+// The candidate set of the many-candidate kernel (traceSequentialGang, experiments build): b.countHist
+// (zeroed once) and b.wideCands (wideCandidateBytes()) - before the trace kernel a one-lane kernel builds
+// the set from the histogram of per-sub-sample draw counts the previous launch left in countHist.
 size_t wideCandidateBytes();
 // traceSequentialGang (several CUs per pass, for renders with fewer passes than CUs): the number of
 // workgroups per pass the dispatcher will use for this launch shape on the current device (0: the
@@ -108,8 +106,6 @@ int seqGangGroups(const TraceParams &p);
 size_t gangRecordBytes(uint32_t npass);
 // Builds the candidate set (n candidates) for the next launch from b.countHist into b.wideCands.
 hipError_t launchBuildCandidates(const TraceParams &p, const TraceBuffers &b, int n, hipStream_t stream);
-hipError_t launchTraceSequentialWide(const TraceParams &p, const TraceBuffers &b, hipStream_t stream,
-                                     const char **variant);
 // PERPIXEL policy: one lane per (pass, pixel) sample.
 hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipStream_t stream,
                                const char **variant = nullptr);

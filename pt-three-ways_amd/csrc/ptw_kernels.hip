@@ -27,10 +27,11 @@
 //      first-bounce fan-out traced speculatively by four waves against a two-block stream ring
 //      that a fifth wave keeps filled (the headline kernel; see the comment at the kernel).
 //
-//  (csrc/experiments/: traceSequentialSpec8, the many-candidate traceSequentialWide and
-//      traceSequentialGang (several CUs per pass) - built, measured no faster on the headline scene
-//       and therefore NOT in the shipped library; `make experiments` builds
-//      them into experiments/libptw_hip.so.)
+//  (csrc/experiments/: traceSequentialGang (several CUs per pass) and the decoupled protocol of the
+//      two-master kernels - built, bit-identical, measured no faster and
+//      therefore NOT in the shipped library; `make experiments` builds them into
+//      experiments/libptw_hip.so.  Round 2's traceSequentialWide / traceSequentialSpec8 (DESIGN.md
+//      3.1c) were retired from the tree in round 4; their last revision is commit 9d6656f.)
 //
 //  tracePerPixel, tracePerPixelPersistent   PERPIXEL policy: one lane per (pass, pixel) sample,
 //      sfc32 stream per sample, triangles streamed wave-uniformly (scalar loads, SGPR operands);
@@ -63,7 +64,7 @@
 #define PTW_SEQ_SELECT 0
 #endif
 // -DPTW_EXPERIMENTS=1 (make experiments): also build the measured-slower opt-in kernels of
-// csrc/experiments/ (traceSequentialWide, traceSequentialSpec8) and their env switches.
+// csrc/experiments/ (traceSequentialGang; the decoupled two-master protocol) and their env switches.
 #ifndef PTW_EXPERIMENTS
 #define PTW_EXPERIMENTS 0
 #endif
@@ -2126,7 +2127,6 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
 
 #if PTW_EXPERIMENTS
 #include "experiments/ptw_gang.h"
-#include "experiments/ptw_spec8.h"
 #endif
 
 // -----------------------------------------------------------------------------------------
@@ -2943,23 +2943,6 @@ hipError_t launchSeqAuto(const TraceParams &p, const TraceBuffers &b, hipStream_
   return launchSeq<SLOTS, WAVES, false, false, MASTERS>(p, b, stream);
 }
 
-#if PTW_EXPERIMENTS
-hipError_t launchSeqSpec8(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
-  tlsVariant = "traceSequentialSpec8";
-  // the candidate set of this launch, from what the previous launch measured
-  hipError_t e = launchBuildCandidates(p, b, kSpec8Waves, stream);
-  if (e != hipSuccess) return e;
-  const size_t lds = spec8LdsBytes(p.ntri, p.nmat, p.nsph);
-  e = hipFuncSetAttribute(reinterpret_cast<const void *>(traceSequentialSpec8),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(traceSequentialSpec8, dim3(p.npass), dim3(64 * kSpec8Waves), lds, stream, p, b.triGeom,
-                     b.spheres, b.triCompact, b.matTable, b.mtState, b.specState, b.stage, b.words, b.rays,
-                     reinterpret_cast<const WideCandidates *>(b.wideCands), b.countHist);
-  return hipGetLastError();
-}
-
-#endif
 
 hipError_t launchSeqSpec(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
   tlsVariant = "traceSequentialSpec";
@@ -3104,19 +3087,6 @@ hipError_t dispatchSequential(const TraceParams &p, const TraceBuffers &b, hipSt
       // PTW_SEQ_GANG=2|4|8: several CUs per pass (experiments/ptw_gang.h)
       if (b.gangRecords && b.countHist && b.wideCands)
         if (const int G = seqGangGroups(p)) return launchSeqGang(p, b, stream, G);
-#endif
-#if PTW_EXPERIMENTS
-      // PTW_SEQ_WIDE=1: the many-candidate form (ptw_wide.hip: 64 candidates per round, 8 lanes each).
-      // Measured on Cornell it does the same work per committed sub-sample as the four-wave form -
-      // what it saves per candidate it spends on candidates that are not needed - and loses on
-      // waiting (profiles/README.md, round 2), so it is not the default.
-      const char *wideEnv = std::getenv("PTW_SEQ_WIDE");
-      if (wideEnv && wideEnv[0] == '1' && b.countHist && b.wideCands && wideKernelApplies(p))
-        return launchTraceSequentialWide(p, b, stream, &tlsVariant);
-      // PTW_SEQ_SPEC8: eight tracing waves, two per SIMD (A/B switch while it is being measured)
-      const char *spec8Env = std::getenv("PTW_SEQ_SPEC8");
-      if (spec8Env && spec8Env[0] == '1' && b.countHist && b.wideCands)
-        return launchSeqSpec8(p, b, stream);
 #endif
       return launchSeqSpec(p, b, stream);
     }

@@ -1,5 +1,5 @@
-// ptw_trace_common.h — device code shared by the radiance kernels of ptw_kernels.hip and
-// ptw_wide.hip: nearest-hit primitives (Scene::intersect*, src/dod/Scene.cpp:13-113), the camera
+// ptw_trace_common.h — device code shared by the radiance kernels of ptw_kernels.hip (and of
+// csrc/experiments/): nearest-hit primitives (Scene::intersect*, src/dod/Scene.cpp:13-113), the camera
 // ray (src/math/Camera.h:20-60) and the std::mt19937 stream ring of the speculative kernels.
 #pragma once
 
@@ -209,7 +209,7 @@ constexpr uint32_t kGenNone = 0, kGenSlot0 = 1, kGenSlot1 = 2, kGenExit = 3;
 
 
 // The candidate set of the many-candidate speculative kernels (device memory, written per band by
-// wideBuildCandidates in ptw_wide.hip from the measured histogram of per-sub-sample draw counts).
+// wideBuildCandidates, experiments/ptw_gang.h, from the measured histogram of per-sub-sample draw counts).
 constexpr int kWideMaxCand = 64;
 struct WideCandidates {
   uint16_t node[kWideMaxCand]; // candidate c = m << 8 | D: sub-sample j + m, D draws after the frontier

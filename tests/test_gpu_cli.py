@@ -69,9 +69,8 @@ def test_chunked_save_every_and_png_and_merge(pkg, tmp_path):
 def test_sequential_kernel_variants_write_identical_bytes(pkg, tmp_path, scene, extra):
     """The speculative four-wave kernel, the single-wave register-stack kernel and the plain
     single-wave kernel are schedules of one computation: same .raw bytes.  A tiny staging budget makes
-    every pass park and resume its stream dozens of times.  The opt-in kernels of the experiments
-    build (wide: 8 or 16 lanes per candidate, full or short candidate list; eight tracing waves)
-    are held to the same bytes when that build is present."""
+    every pass park and resume its stream dozens of times.  The opt-in kernel of the experiments
+    build (several CUs per pass) is held to the same bytes when that build is present."""
     from conftest import ROOT
     args = ["-w", "40", "-h", "28", "--spp", "5", "--seed", "11", "--scene", scene, "--raw", "--save-every", "0"] + extra
     variants = {"spec": {}, "reg": {"PTW_SEQ_SPEC": "0"}, "plain": {"PTW_SEQ_SPEC": "0", "PTW_SEQ_REG": "0"},
@@ -80,10 +79,6 @@ def test_sequential_kernel_variants_write_identical_bytes(pkg, tmp_path, scene, 
     exp = {"PTW_USE_EXPERIMENTS": "1"}
     if (pkg.LIB_PATH.parent / "experiments" / "libptw_hip.so").exists() and not extra:
         variants.update({
-            "spec8": dict(exp, PTW_SEQ_SPEC8="1"), "spec8_bands": dict(exp, PTW_SEQ_SPEC8="1", PTW_STAGE_BUDGET_KB="12"),
-            "wide8": dict(exp, PTW_SEQ_WIDE="1", PTW_WIDE_G="8"), "wide16": dict(exp, PTW_SEQ_WIDE="1", PTW_WIDE_G="16"),
-            "wide8_few": dict(exp, PTW_SEQ_WIDE="1", PTW_WIDE_CANDIDATES="5"),
-            "wide_bands": dict(exp, PTW_SEQ_WIDE="1", PTW_STAGE_BUDGET_KB="12"),
             "gang8": dict(exp, PTW_SEQ_GANG="8"), "gang4_bands": dict(exp, PTW_SEQ_GANG="4", PTW_STAGE_BUDGET_KB="12"),
             "gang2": dict(exp, PTW_SEQ_GANG="2")})
     blobs = {}
@@ -104,11 +99,15 @@ def test_two_master_worker_kernel_writes_identical_bytes(pkg, tmp_path, scene, s
     args = ["-w", "24", "-h", "18", "--spp", str(spp), "--seed", "4", "--scene", scene, "--raw", "--save-every", "0"]
     variants = {"one": {"PTW_SEQ_MM": "0"}, "two": {"PTW_SEQ_MM": "1"},
                 "two_bands": {"PTW_SEQ_MM": "1", "PTW_STAGE_BUDGET_KB": "8"}}
+    if (pkg.LIB_PATH.parent / "experiments" / "libptw_hip.so").exists():   # the decoupled protocol (round 4)
+        variants["two_decoupled"] = {"PTW_USE_EXPERIMENTS": "1", "PTW_SEQ_MM": "1"}
+        variants["two_decoupled_bands"] = {"PTW_USE_EXPERIMENTS": "1", "PTW_SEQ_MM": "1", "PTW_STAGE_BUDGET_KB": "8"}
     blobs = {}
     for name, env in variants.items():
         out = run_cli(pkg, args + [str(tmp_path / f"{name}.raw")], ROOT, env=env)
         blobs[name] = (tmp_path / f"{name}.raw").read_bytes()
-    assert blobs["two"] == blobs["one"] and blobs["two_bands"] == blobs["one"]
+    for name in variants:
+        assert blobs[name] == blobs["one"], name
 
 
 @pytest.mark.parametrize("scene", ["cornell", "suzanne", "multi-sphere"])
