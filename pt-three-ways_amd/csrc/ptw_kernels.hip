@@ -76,6 +76,20 @@
 #ifndef PTW_SEQ_CHAIN_MASTER
 #define PTW_SEQ_CHAIN_MASTER 1
 #endif
+// Round 4 (make alt ALT_FLAGS="-DPTW_SEQ_PICK_MIN=0 -DPTW_SEQ_LDS_MIN=0" restores round 3's forms):
+//  PICK_MIN  the master's pick over the workers' answers as "minimum distance, then the lowest index
+//            among the answers that have it" (five v_min_f64, six compare-and-select, three v_min3_u32)
+//            instead of five lexicographic compare-and-select steps of ten instructions each;
+//  LDS_MIN   a worker wave whose lanes hold three or more candidates finds the nearest with ONE LDS
+//            atomic (ds_min_u64 on the distance's bit pattern, in a slot of its own) instead of two
+//            64-lane DPP reductions: the worker waves sit two to a SIMD, where every VALU instruction
+//            not issued is a slot for the other wave.
+#ifndef PTW_SEQ_PICK_MIN
+#define PTW_SEQ_PICK_MIN 1
+#endif
+#ifndef PTW_SEQ_LDS_MIN
+#define PTW_SEQ_LDS_MIN 1
+#endif
 // Two masters per workgroup: 0 = round 2's lock step, one barrier sequence for both masters (the
 // shipped form); 1 = the masters do not wait for each other - the workers poll both masters' request
 // words and answer whichever has a ray ready, no workgroup barrier on the ray path (round 4: built,
@@ -330,13 +344,49 @@ struct SeqShared {
 // `det < epsilon` of Scene.cpp:107 - in bit 31 (kMiss, all ones, with t = +inf for "nothing hit").
 struct alignas(16) PartialHit {
   double t;
-  uint32_t idxSign;
+  uint32_t idxSign; // combined index << 1 | (det < epsilon); kMiss (all ones) with t = +inf for "nothing"
   uint32_t pad;
 };
+__device__ __forceinline__ uint32_t packAnswer(const HitKey &k) {
+  return k.idx == kMiss ? kMiss : ((k.idx << 1) | (k.det < kEpsilon ? 1u : 0u));
+}
+// The nearest of n answers with the reference's tie-break (strictly nearer wins, an exact tie goes to
+// the lower combined index: Scene.cpp:31,95,118), computed by every lane alike - no cross-lane traffic.
+template <int N>
+__device__ __forceinline__ HitKey pickOfAnswers(const PartialHit (&ph)[N]) {
+  HitKey key;
+#if PTW_SEQ_PICK_MIN
+  // the minimum distance, then the lowest packed index among the answers that have it (the packing
+  // keeps the order of the indices; a miss is +inf / all ones and loses against everything)
+  double bt = ph[0].t;
+#pragma unroll
+  for (int w = 1; w < N; ++w) bt = vmin64(bt, ph[w].t);
+  uint32_t bw = kMiss;
+#pragma unroll
+  for (int w = 0; w < N; ++w) {
+    const uint32_t c = ph[w].t == bt ? ph[w].idxSign : kMiss;
+    bw = c < bw ? c : bw;
+  }
+#else
+  double bt = ph[0].t;
+  uint32_t bw = ph[0].idxSign;
+#pragma unroll
+  for (int w = 1; w < N; ++w) {
+    const bool take = (ph[w].t < bt) | ((ph[w].t == bt) & (ph[w].idxSign < bw));
+    bt = take ? ph[w].t : bt;
+    bw = take ? ph[w].idxSign : bw;
+  }
+#endif
+  key.t = bt;
+  key.idx = bw == kMiss ? kMiss : (bw >> 1);
+  key.det = (bw & 1u) ? -1.0 : 1.0; // (only its sign test is ever used)
+  return key;
+}
 // Behind the answers: the masters' commands (64 bytes each: ray + request number), then - decoupled
 // protocol - one word per (master, worker): the request number the worker's answer belongs to.
 constexpr size_t kSeqCmdBytes = 256;
 constexpr size_t kSeqFlagsOffset = 128; // into the command area; [MASTERS][8] words
+constexpr size_t kSeqMinSlotOffset = 192; // ... then 8 bytes per worker wave (pickNearest's LDS atomic)
 constexpr uint32_t kSeqDone = 0xffffffffu; // request word of a master that has no more rays
 
 // Master -> worker request of the multi-wave sequential kernel.
@@ -477,6 +527,7 @@ struct SeqCtx {
   // second" on the writing side and "number first, data second" on the reading side is all the
   // ordering there is - no workgroup barrier on the ray path.
   static constexpr bool kDecoupled = PTW_SEQ_DECOUPLED && MASTERS == 2;
+  unsigned long long *minSlot; // worker waves: this wave's 8 bytes of LDS for pickNearest's atomic form
   uint32_t *flags;       // [MASTERS][8] in LDS
   uint32_t seq;          // master: number of its current request (never 0, never kSeqDone)
   int masterIndex;
@@ -664,7 +715,10 @@ struct SeqCtx {
 
   // The nearest of the lanes' candidates (t, combined index, determinant) with the reference's
   // tie-break, as a wave-uniform result.
-  __device__ __forceinline__ static HitKey pickNearest(double bestT, uint32_t bestIdx, double bestDet) {
+  // `slot`: the calling wave's 8 bytes of LDS for the atomic form of the many-candidates case (worker
+  // waves), nullptr for the DPP form.
+  __device__ __forceinline__ static HitKey pickNearest(double bestT, uint32_t bestIdx, double bestDet,
+                                                        unsigned long long *slot = nullptr) {
     HitKey key;
     // Most rays leave at most two lanes with a candidate (the line through a closed scene crosses
     // few primitives on its positive side): pick the nearer of them with scalar code instead of
@@ -698,7 +752,25 @@ struct SeqCtx {
       // scalar compares each - measured slower: Cornell 7.28 against 7.69 Msamples/s,
       // profiles/r02r_pick_loop_probe.txt)
       unsigned tHi, tLo;
-      const double tmin = waveMinPositive(bestT, tHi, tLo);
+      double tmin;
+      if (PTW_SEQ_LDS_MIN && WAVES > 1 && slot) {
+        // Distances are positive doubles: their bit patterns order like unsigned 64-bit integers.  The
+        // first candidate lane resets the slot, every candidate lane folds its distance in with one
+        // ds_min_u64, everybody reads the result - three LDS instructions of one wave to one address,
+        // served in order - instead of twelve DPP steps.
+        typedef unsigned long long __attribute__((address_space(3))) LdsU64;
+        LdsU64 *ls = (LdsU64 *)(slot);
+        const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(bestT));
+        if (static_cast<int>(threadIdx.x & 63) == __builtin_ctzll(cands)) *(volatile LdsU64 *)ls = ~0ull;
+        asm volatile("" ::: "memory");
+        if (bestIdx != kMiss) (void)__hip_atomic_fetch_min(ls, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        asm volatile("" ::: "memory");
+        const unsigned long long tb = *(volatile LdsU64 *)ls;
+        tHi = static_cast<unsigned>(tb >> 32), tLo = static_cast<unsigned>(tb);
+        tmin = __longlong_as_double(static_cast<long long>(tb));
+      } else {
+        tmin = waveMinPositive(bestT, tHi, tLo);
+      }
       unsigned long long owner = __builtin_amdgcn_ballot_w64(
           static_cast<unsigned>(hi32(bestT)) == tHi && static_cast<unsigned>(lo32(bestT)) == tLo);
       if (__builtin_popcountll(owner) != 1) { // exact tie between lanes: lowest combined index wins
@@ -769,7 +841,7 @@ struct SeqCtx {
 #endif
     PTW_T(tB);
     PTW_ACC(0, tA, tB);
-    HitKey key = pickNearest(bestT, bestIdx, bestDet);
+    HitKey key = pickNearest(bestT, bestIdx, bestDet, WAVES > 1 ? minSlot : nullptr);
 #if PTW_PROFILE_PHASES
     asm volatile("" : "+v"(key.t));
 #endif
@@ -828,19 +900,7 @@ struct SeqCtx {
     PartialHit ph[WAVES];
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) ph[w] = partials[w];
-    double bt = ph[0].t;
-    uint32_t bw = ph[0].idxSign;
-#pragma unroll
-    for (int w = 1; w < WAVES; ++w) {
-      const bool take = (ph[w].t < bt) | ((ph[w].t == bt) & ((ph[w].idxSign & 0x7fffffffu) < (bw & 0x7fffffffu)));
-      bt = take ? ph[w].t : bt;
-      bw = take ? ph[w].idxSign : bw;
-    }
-    HitKey key;
-    key.t = bt;
-    key.idx = bw == kMiss ? kMiss : (bw & 0x7fffffffu);
-    key.det = (bw >> 31) ? -1.0 : 1.0; // (only its sign test is ever used)
-    return key;
+    return pickOfAnswers(ph);
   }
 
   // Scene::intersect for the whole workgroup.  WAVES == 1: the wave's own result.  WAVES > 1:
@@ -906,18 +966,7 @@ struct SeqCtx {
         __builtin_amdgcn_s_sleep(PTW_SEQ_POLL_SLEEP);
       }
       PTW_T(tDc);
-      double bt = ph[0].t;
-      uint32_t bw = ph[0].idxSign;
-#pragma unroll
-      for (int w = 1; w < WAVES; ++w) {
-        const bool take = (ph[w].t < bt) | ((ph[w].t == bt) & ((ph[w].idxSign & 0x7fffffffu) < (bw & 0x7fffffffu)));
-        bt = take ? ph[w].t : bt;
-        bw = take ? ph[w].idxSign : bw;
-      }
-      HitKey key;
-      key.t = bt;
-      key.idx = bw == kMiss ? kMiss : (bw & 0x7fffffffu);
-      key.det = (bw >> 31) ? -1.0 : 1.0; // (only its sign test is ever used)
+      HitKey key = pickOfAnswers(ph);
 #if PTW_PROFILE_PHASES
       asm volatile("" : "+v"(key.t));
       const unsigned long long tDd = __builtin_amdgcn_s_memtime();
@@ -962,7 +1011,7 @@ struct SeqCtx {
     uint32_t cidx = kMiss;
     if ((threadIdx.x & 63) < WAVES) {
       const PartialHit ph = partials[threadIdx.x & 63];
-      ct = ph.t, cidx = ph.idxSign == kMiss ? kMiss : (ph.idxSign & 0x7fffffffu), cdet = (ph.idxSign >> 31) ? -1.0 : 1.0;
+      ct = ph.t, cidx = ph.idxSign == kMiss ? kMiss : (ph.idxSign >> 1), cdet = (ph.idxSign & 1u) ? -1.0 : 1.0;
     }
     const HitKey key = pickNearest(ct, cidx, cdet);
 #endif
@@ -1015,7 +1064,7 @@ struct SeqCtx {
         if ((tid & 63) == 0) {
           PartialHit ph;
           ph.t = found.t, ph.pad = 0;
-          ph.idxSign = found.idx == kMiss ? kMiss : (found.idx | (found.det < kEpsilon ? 0x80000000u : 0u));
+          ph.idxSign = packAnswer(found);
           partials[m * WAVES + (tid >> 6)] = ph;
           asm volatile("" ::: "memory");
           *reinterpret_cast<volatile uint32_t *>(flags + m * 8 + (tid >> 6)) = sm;
@@ -1047,7 +1096,7 @@ struct SeqCtx {
         if ((tid & 63) == 0) {
           PartialHit ph;
           ph.t = found.t, ph.pad = 0;
-          ph.idxSign = found.idx == kMiss ? kMiss : (found.idx | (found.det < kEpsilon ? 0x80000000u : 0u));
+          ph.idxSign = packAnswer(found);
           partials[(n & 1) * WAVES + (tid >> 6)] = ph;
         }
 #if PTW_PROFILE_PHASES
@@ -1064,7 +1113,7 @@ struct SeqCtx {
       if ((tid & 63) == 0) {
         PartialHit ph;
         ph.t = mine.t, ph.pad = 0;
-        ph.idxSign = mine.idx == kMiss ? kMiss : (mine.idx | (mine.det < kEpsilon ? 0x80000000u : 0u));
+        ph.idxSign = packAnswer(mine);
         partials[tid >> 6] = ph;
       }
 #if PTW_PROFILE_PHASES
@@ -1573,10 +1622,12 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
   ctx.partials = isWorker ? partials : partials + master * WAVES;
   ctx.cmd = ctx.allCmds + master;
   ctx.flags = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(ctx.allCmds) + kSeqFlagsOffset);
+  ctx.minSlot = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(ctx.allCmds) + kSeqMinSlotOffset) +
+                (isWorker ? static_cast<int>(threadIdx.x >> 6) - MASTERS : 0);
   ctx.seq = 0;
   ctx.masterIndex = master;
   static_assert(MASTERS * sizeof(SeqCommand) <= kSeqFlagsOffset && kSeqFlagsOffset + MASTERS * 8 * sizeof(uint32_t) <= kSeqCmdBytes &&
-                    WAVES <= 8, "commands and answer numbers fit");
+                    WAVES <= 8 && kSeqMinSlotOffset + 8 * sizeof(unsigned long long) <= kSeqCmdBytes, "commands, answer numbers and slots fit");
   ctx.tick = 0;
   ctx.laArmed = false;
   ctx.laPos = -1;
