@@ -96,7 +96,7 @@ struct ptw_context {
   std::vector<uint32_t> hostSeedStates, hostPos;
   hipEvent_t uploadsDone = nullptr; // recorded after a render's uploads: the host vectors are free again
   // PERPIXEL: which of the two kernels this scene + frame shape runs faster on (timed once, see
-  // choosePixKernel); 0 = not decided yet
+  // ptw_context_calibrate / calibratePixKernel); 0 = not decided yet
   uint64_t pixChoiceKey = 0;
   int pixChoice = 0;
   uint64_t sceneGeneration = 0;

@@ -3192,9 +3192,9 @@ hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipS
   //     shading code runs once per level for all of them;
   //   persistent (tracePerPixelPersistent, lanes that finish a path take the next sample): suzanne
   //     44 against 19, bbc-owl 395 against 139 - open scenes, where most paths of a wave end early.
-  // p.pixKernel carries the caller's choice (capi_render.hip times a trial of both once per scene
-  // and frame shape); without one the persistent kernel runs.  PTW_PIX_KERNEL (legacy|persistent)
-  // overrides for A/B runs; the accelerated mode has its own kernel.
+  // p.pixKernel carries the caller's choice (ptw_render_params.pix_kernel, or what ptw_context_calibrate
+  // measured for this scene and frame shape; the persistent kernel when neither).  PTW_PIX_KERNEL
+  // (legacy|persistent) overrides for A/B runs; the accelerated mode has its own kernel.
   const char *forced = std::getenv("PTW_PIX_KERNEL");
   if (p.accel == PTW_ACCEL_BVH) {
     if (variant) *variant = "tracePerPixelBvh";
