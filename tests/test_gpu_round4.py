@@ -289,9 +289,9 @@ def test_decoupled_two_master_protocol_matches_oracle(pkg, tmp_path):
 def test_worker_wave_kernels_resolve_exact_ties_like_the_reference(pkg, ob, monkeypatch, masters, spp):
     """Scene::intersect scans the primitives in insertion order with a strict `<` (Scene.cpp:31,95,118):
     of several primitives hit at EXACTLY the same distance the one inserted first wins - and its
-    material decides the path.  A scene of 420 large triangles of which every one has up to two copies
-    with OTHER materials inserted later lands its copies in other units of 64 - other worker waves, other
-    slots of the same lane, and the lanes of one wave - so that the master's pick over the workers' answers
+    material decides the path.  A scene of 140 large triangles, each with a copy 20 indices later (the
+    same unit of 64 triangles: another lane of the same worker wave) and a far copy (another worker wave),
+    all with OTHER materials, so that the master's pick over the workers' answers
     ("the minimum distance, then the lowest index among the answers that have it"), the workers' own
     three-or-more-candidates reduction (one LDS atomic on the distance, then the lowest index among the
     lanes that hold it) and the two-candidates shortcut all meet exact ties on most rays.  Against the
@@ -303,11 +303,12 @@ def test_worker_wave_kernels_resolve_exact_ties_like_the_reference(pkg, ob, monk
             pkg.material("diffuse", (0.2, 0.9, 0.2)), pkg.material("glossy", (0.4, 0.4, 0.9), 1.3, 25.0),
             pkg.material("reflective", (0.8, 0.8, 0.8), 0.6, 6.0)]
     base = rng.uniform(-2.5, 2.5, (140, 3)) [:, None, :] + rng.uniform(-1.6, 1.6, (140, 3, 3))
-    for k, t in enumerate(base):
-        scene.add_triangle(*t, mats[k % 5])
-    for shift in (1, 3):                      # the copies: same geometry, other material, higher index
-        for k, t in enumerate(base):
-            scene.add_triangle(*t, mats[(k + shift) % 5])
+    for b in range(7):                        # blocks of 20 triangles, each followed by its 20 copies (other
+        for shift in (0, 1):                  # material, index + 20: the same unit of 64, another lane)
+            for k in range(20 * b, 20 * b + 20):
+                scene.add_triangle(*base[k], mats[(k + shift) % 5])
+    for k, t in enumerate(base):              # ... and a far copy of every one (another worker wave)
+        scene.add_triangle(*t, mats[(k + 3) % 5])
     scene.add_sphere((0, 0, 0), 9.0, mats[0])   # a shell: long paths
     scene.add_sphere((0, 0, 0), 9.0, mats[2])   # ... and its copy: a tie between spheres
     scene.set_environment_colour((0.1, 0.2, 0.3))
