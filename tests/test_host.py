@@ -238,3 +238,20 @@ def test_png_writer_produces_a_valid_png(pkg, tmp_path):
     assert struct.unpack(">IIBBBBB", chunks[0][1]) == (53, 37, 8, 2, 0, 0, 0)
     rows = np.frombuffer(zlib.decompress(chunks[1][1]), dtype=np.uint8).reshape(37, 1 + 53 * 3)
     assert not rows[:, 0].any() and np.array_equal(rows[:, 1:].reshape(37, 53, 3), img)
+
+
+def test_bench_gpus_n_without_enough_gpus_says_so():
+    """`python bench.py --gpus N` outside torch.distributed.run launches its N ranks itself; with fewer
+    GPUs than ranks (here: none) it refuses with exit code 2 and a message instead of rendering on one
+    GPU and reporting it as N (round 3's silent degradation)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PTW_BENCH_SHARE_GPU")}
+    import torch
+    n = torch.cuda.device_count() + 2
+    proc = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(n), "--width", "8", "--height", "8",
+                           "--spp", "1"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert proc.returncode == 2, proc.stdout + proc.stderr
+    assert "GPU(s) are visible" in proc.stderr and not [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
