@@ -28,12 +28,12 @@
 
 #include <dlfcn.h>
 
-#include <future>
-
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -122,8 +122,10 @@ std::chrono::milliseconds collectiveTimeout(int32_t timeoutMs = 0) {
 // stream watchdog reaches.  So they run on a helper thread; if that thread is not back within the
 // timeout, the caller aborts the communicator from here - ncclCommAbort is the one RCCL call that
 // may be made while another thread is inside the library, and it is what unblocks that thread.
+// (The handle is an atomic: whoever exchanges it for null - this function's timeout path, or
+// ptw_comm_abort on another thread - is the one caller of ncclCommAbort.)
 template <typename Body>
-void runAbortable(ncclComm_t &comm, int device, const char *what, Body &&body) {
+void runAbortable(std::atomic<ncclComm_t> &comm, int device, const char *what, Body &&body) {
   std::promise<void> done;
   std::future<void> fut = done.get_future();
   std::thread helper([&] {
@@ -136,9 +138,7 @@ void runAbortable(ncclComm_t &comm, int device, const char *what, Body &&body) {
     }
   });
   if (fut.wait_for(collectiveTimeout()) != std::future_status::ready) {
-    const ncclComm_t c = comm;
-    comm = nullptr;
-    (void)rccl().commAbort(c);
+    if (const ncclComm_t c = comm.exchange(nullptr)) (void)rccl().commAbort(c);
     helper.join();
     throw DeviceError(PTW_ERR_HIP, std::string(what) + " did not return within the timeout (a peer that never "
                                        "arrived?): communicator aborted");
@@ -209,7 +209,7 @@ __global__ void loopAccumulateU32(uint32_t *__restrict__ dst, const uint32_t *__
 using namespace ptw;
 
 struct ptw_comm {
-  ncclComm_t comm = nullptr;          // RCCL transport
+  std::atomic<ncclComm_t> comm{nullptr}; // RCCL transport (null once aborted: see runAbortable)
   std::shared_ptr<LoopbackHub> hub;   // loopback transport (comm == nullptr)
   // loopback: one `ready` event per (destination, channel) and one `consumed` event per (source,
   // channel), created on first use and re-recorded for every message - a long-lived communicator
@@ -224,7 +224,7 @@ struct ptw_comm {
     if (pack) (void)hipFree(pack);
     for (hipEvent_t e : events)
       if (e) (void)hipEventDestroy(e);
-    if (comm) (void)rccl().commDestroy(comm);
+    if (const ncclComm_t c = comm.exchange(nullptr)) (void)rccl().commDestroy(c);
   }
   hipEvent_t eventFor(int kind, int peer, int channel) { // kind 0: ready (send), 1: consumed (recv)
     if (events.empty()) events.assign(static_cast<size_t>(world) * 4, nullptr);
@@ -323,7 +323,9 @@ int ptw_comm_create(const uint8_t id[PTW_COMM_ID_BYTES], int32_t world_size, int
   c->device = device;
   ncclUniqueId uid;
   std::memcpy(uid.internal, id, PTW_COMM_ID_BYTES);
-  checkNccl(rccl().commInitRank(&c->comm, world_size, uid, rank), "ncclCommInitRank");
+  ncclComm_t raw = nullptr;
+  checkNccl(rccl().commInitRank(&raw, world_size, uid, rank), "ncclCommInitRank");
+  c->comm = raw;
   *out = c.release();
   return PTW_OK;
   PTW_GUARD_END
@@ -370,10 +372,8 @@ int ptw_comm_abort(ptw_comm *comm) {
   PTW_GUARD_BEGIN
   if (comm->hub) {
     comm->hub->abort();
-  } else if (comm->comm) {
+  } else if (const ncclComm_t c = comm->comm.exchange(nullptr)) {
     // ncclCommAbort frees the communicator: kernels of it that wait for a peer on the device end
-    const ncclComm_t c = comm->comm;
-    comm->comm = nullptr;
     checkNccl(rccl().commAbort(c), "ncclCommAbort");
   }
   return PTW_OK;
@@ -404,9 +404,9 @@ int ptw_comm_wait(ptw_comm *comm, void *hip_stream, int32_t timeout_ms) {
         aborted = comm->hub->aborted;
       }
       if (aborted) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
-    } else if (comm->comm) {
+    } else if (const ncclComm_t nc = comm->comm.load()) {
       ncclResult_t async = ncclSuccess;
-      const ncclResult_t r = rccl().commGetAsyncError(comm->comm, &async);
+      const ncclResult_t r = rccl().commGetAsyncError(nc, &async);
       if (r != ncclSuccess) giveUp(std::string("ncclCommGetAsyncError: ") + rccl().getErrorString(r));
       if (async != ncclSuccess && async != ncclInProgress)
         giveUp(std::string("asynchronous RCCL error: ") + rccl().getErrorString(async));
@@ -451,9 +451,9 @@ int ptw_comm_reduce_framebuffer(ptw_comm *comm, void *d_rgb_sum, void *d_counts,
     }
     return PTW_OK;
   }
-  if (!comm->comm) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
+  const ncclComm_t nc = comm->comm.load();
+  if (!nc) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
   const Rccl &api = rccl();
-  const ncclComm_t nc = comm->comm;
   runAbortable(comm->comm, comm->device, "ncclReduce of the framebuffer", [&] {
     // one group: both reductions are launched together
     checkNccl(api.groupStart(), "ncclGroupStart");
@@ -478,7 +478,8 @@ int ptw_comm_gather_rows(ptw_comm *comm, void *d_rgb_sum, void *d_counts, int32_
   const int world = comm->world, rank = comm->rank;
   if (world == 1) return PTW_OK;
   const bool loop = static_cast<bool>(comm->hub);
-  if (!loop && !comm->comm) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
+  const ncclComm_t nc = loop ? nullptr : comm->comm.load();
+  if (!loop && !nc) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
   const Rccl *api = loop ? nullptr : &rccl();
   const size_t w = static_cast<size_t>(width);
   const size_t rgbRow = w * 3 * sizeof(double), cntRow = w * sizeof(uint32_t);
@@ -506,7 +507,6 @@ int ptw_comm_gather_rows(ptw_comm *comm, void *d_rgb_sum, void *d_counts, int32_
       }
       return PTW_OK;
     }
-    const ncclComm_t nc = comm->comm;
     runAbortable(comm->comm, comm->device, "ncclSend of the rows", [&] {
       checkNccl(api->groupStart(), "ncclGroupStart");
       if (rows) {
@@ -532,7 +532,6 @@ int ptw_comm_gather_rows(ptw_comm *comm, void *d_rgb_sum, void *d_counts, int32_
       });
     }
   } else {
-    const ncclComm_t nc = comm->comm;
     runAbortable(comm->comm, comm->device, "ncclRecv of the rows", [&] {
       checkNccl(api->groupStart(), "ncclGroupStart");
       for (int r = 0; r < world; ++r) {
