@@ -202,7 +202,6 @@ __global__ __launch_bounds__(64 * kGangWaves) void traceSequentialGang(
   ctx.words = 0;
   ctx.rays = 0;
   ctx.parity = 0;
-  ctx.minSlot = nullptr; // (pickNearest: the DPP form)
   ctx.ringBase = ring;
   {
     SphereRec *ls = reinterpret_cast<SphereRec *>(ldsRaw + off);

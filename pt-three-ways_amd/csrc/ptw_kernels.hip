@@ -90,11 +90,6 @@
 #ifndef PTW_SEQ_LDS_MIN
 #define PTW_SEQ_LDS_MIN 1
 #endif
-// ... the same for the tracing waves of traceSequentialSpec (a wave alone on its SIMD: two LDS round
-// trips against twelve DPP steps; A/B switch)
-#ifndef PTW_SPEC_LDS_MIN
-#define PTW_SPEC_LDS_MIN 0
-#endif
 // Two masters per workgroup: 0 = round 2's lock step, one barrier sequence for both masters (the
 // shipped form); 1 = the masters do not wait for each other - the workers poll both masters' request
 // words and answer whichever has a ray ready, no workgroup barrier on the ray path (round 4: built,
@@ -758,7 +753,7 @@ struct SeqCtx {
       // profiles/r02r_pick_loop_probe.txt)
       unsigned tHi, tLo;
       double tmin;
-      if (((PTW_SEQ_LDS_MIN && WAVES > 1) || (PTW_SPEC_LDS_MIN && SPEC)) && slot) {
+      if (PTW_SEQ_LDS_MIN && WAVES > 1 && slot) {
         // Distances are positive doubles: their bit patterns order like unsigned 64-bit integers.  The
         // first candidate lane resets the slot, every candidate lane folds its distance in with one
         // ds_min_u64, everybody reads the result - three LDS instructions of one wave to one address,
@@ -846,7 +841,7 @@ struct SeqCtx {
 #endif
     PTW_T(tB);
     PTW_ACC(0, tA, tB);
-    HitKey key = pickNearest(bestT, bestIdx, bestDet, (WAVES > 1 || (PTW_SPEC_LDS_MIN && SPEC)) ? minSlot : nullptr);
+    HitKey key = pickNearest(bestT, bestIdx, bestDet, WAVES > 1 ? minSlot : nullptr);
 #if PTW_PROFILE_PHASES
     asm volatile("" : "+v"(key.t));
 #endif
@@ -1868,8 +1863,6 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
   ctx.rays = 0;
   ctx.parity = 0;
   ctx.ringBase = ring;
-  // (8 bytes per tracing wave behind the two generator command words, inside their 64 bytes)
-  ctx.minSlot = reinterpret_cast<unsigned long long *>(ldsRaw + kGenCmdOffset + 16) + (wave < kSpecWaves ? wave : 0);
   {
     SphereRec *ls = reinterpret_cast<SphereRec *>(ldsRaw + off);
     double *lt = reinterpret_cast<double *>(ls + p.nsph);
