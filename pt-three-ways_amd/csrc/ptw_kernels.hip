@@ -1122,10 +1122,10 @@ struct SeqCtx {
       ldsBarrier(); // B2
     }
 #if PTW_PROFILE_PHASES
-    if (blockIdx.x == 0 && tid == 0) {
+    if (blockIdx.x == 0 && (tid & 63) == 0) { // every worker wave: which ones are the slow ones?
       const unsigned long long w1 = __builtin_amdgcn_s_memtime();
-      printf("WORKER requests=%llu total/req=%.0f tests=%.0f reduce=%.0f\n", nreq,
-             (double)(w1 - w0) / nreq, (double)prof[0] / nreq, (double)prof[1] / nreq);
+      printf("WORKER rank=%d (hardware wave %d, %d units) requests=%llu total/req=%.0f tests=%.0f reduce=%.0f\n", tid >> 6,
+             (int)(threadIdx.x >> 6), myUnits, nreq, (double)(w1 - w0) / nreq, (double)prof[0] / nreq, (double)prof[1] / nreq);
     }
 #endif
   }
