@@ -38,6 +38,10 @@ struct TraceParams {
   // for the waves that share a SIMD with another worker, seqUnitsB for those beside a master wave
   // (set by the launcher, see seqUnitSplit)
   int32_t seqUnitsA, seqUnitsB;
+  // ... and, among the waves that share a SIMD with another worker, the YOUNGER one of each pair (the
+  // arbiter serves the older wave first: round 4 measured the younger ones 35-40 % slower per triangle,
+  // profiles/r04k_*): seqUnitsA is then the older wave's share.  Equal to seqUnitsA by default.
+  int32_t seqUnitsY;
 };
 constexpr int kPixKernelAuto = 0, kPixKernelLockstep = 1, kPixKernelPersistent = 2;
 

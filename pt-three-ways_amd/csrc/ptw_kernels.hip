@@ -49,6 +49,7 @@
 //      ptw_context_rng_doubles).
 #include "ptw_trace_common.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -563,7 +564,7 @@ struct SeqCtx {
   __device__ __forceinline__ uint32_t residentTriangles() const {
     if (WAVES == 1) return static_cast<uint32_t>(kThreads) * SLOTS;
     constexpr int nB = MASTERS, nA = WAVES - MASTERS;
-    return static_cast<uint32_t>(nA * p->seqUnitsA + nB * p->seqUnitsB) * 64u;
+    return static_cast<uint32_t>((nA / 2) * (p->seqUnitsA + p->seqUnitsY) + nB * p->seqUnitsB) * 64u;
   }
 
   __device__ __forceinline__ void loadPrimitives() {
@@ -1612,9 +1613,15 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
     // ranks [0, nA): the workers that share a SIMD with another worker; [nA, WAVES): beside a master
     constexpr int nA = WAVES - MASTERS;
     const bool sideB = workerRank >= nA;
-    ctx.myUnits = __builtin_amdgcn_readfirstlane(sideB ? p.seqUnitsB : p.seqUnitsA);
-    ctx.unitBase = __builtin_amdgcn_readfirstlane(sideB ? nA * p.seqUnitsA + (workerRank - nA) * p.seqUnitsB
-                                                        : workerRank * p.seqUnitsA);
+    // ranks [0, nA / 2): the OLDER wave of each worker pair (lower hardware wave index), [nA / 2, nA):
+    // the younger one
+    static_assert(nA % 2 == 0, "the worker-only SIMDs carry two workers each");
+    const bool young = !sideB && workerRank >= nA / 2;
+    ctx.myUnits = __builtin_amdgcn_readfirstlane(sideB ? p.seqUnitsB : (young ? p.seqUnitsY : p.seqUnitsA));
+    ctx.unitBase = __builtin_amdgcn_readfirstlane(
+        sideB   ? (nA / 2) * (p.seqUnitsA + p.seqUnitsY) + (workerRank - nA) * p.seqUnitsB
+        : young ? (nA / 2) * p.seqUnitsA + (workerRank - nA / 2) * p.seqUnitsY
+                : workerRank * p.seqUnitsA);
   }
   ctx.stack = stacks + master * depthSlots; // only the master waves use a radiance stack
   // [MASTERS][WAVES] partial results, then the commands (56 B each)
@@ -2956,14 +2963,27 @@ int seqBalanceRatio(int masters) {
   return masters == 2 ? PTW_SEQ_BALANCE_MM : PTW_SEQ_BALANCE_ONE;
 }
 
+// The units of 64 triangles per worker wave: older / younger wave of a worker pair, master-side wave.
+// seqUnitSplit's equal-or-ratio shares by default; PTW_SEQ_UNITS="o,y,m" sets them outright (A/B
+// runs; what does not fit the waves' shares is streamed from memory).
+void seqUnitsFor(uint32_t ntri, int nA, int nB, int ratio, int cap, int &uO, int &uY, int &uM) {
+  int uA, uB;
+  seqUnitSplit(ntri, nA, nB, ratio, cap, uA, uB);
+  uO = uY = uA, uM = uB;
+  if (const char *v = std::getenv("PTW_SEQ_UNITS")) {
+    int o = -1, y = -1, m = -1;
+    if (std::sscanf(v, "%d,%d,%d", &o, &y, &m) == 3 && o >= 0 && y >= 0 && m >= 0 && o <= cap && y <= cap && m <= cap)
+      uO = o, uY = y, uM = m;
+  }
+}
+
 template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false, int MASTERS = 1>
 hipError_t launchSeq(const TraceParams &pIn, const TraceBuffers &b, hipStream_t stream) {
   TraceParams p = pIn;
   if (WAVES > 1) {
-    int uA, uB;
-    seqUnitSplit(p.ntri, WAVES - MASTERS, MASTERS, seqBalanceRatio(MASTERS), SLOTS, uA, uB);
-    p.seqUnitsA = uA, p.seqUnitsB = uB;
-
+    int uO, uY, uM;
+    seqUnitsFor(p.ntri, WAVES - MASTERS, MASTERS, seqBalanceRatio(MASTERS), SLOTS, uO, uY, uM);
+    p.seqUnitsA = uO, p.seqUnitsY = uY, p.seqUnitsB = uM;
   }
   auto kernel = traceSequential<SLOTS, WAVES, LDS_TABLES, REG, MASTERS>;
   std::snprintf(tlsVariantBuf, sizeof tlsVariantBuf, "traceSequential<%d,%d,%s,%s%s>", SLOTS, WAVES,
@@ -3159,20 +3179,21 @@ hipError_t dispatchSequential(const TraceParams &p, const TraceBuffers &b, hipSt
   // spilling inside the search loop (11 units = 198 registers), the rest of a larger scene is
   // streamed from memory.
   if (mm) {
-    int uA, uB;
-    seqUnitSplit(n, 4, 2, seqBalanceRatio(2), 11, uA, uB);
-    const int need = uA > uB ? uA : uB;
+    int uO, uY, uM;
+    seqUnitsFor(n, 4, 2, seqBalanceRatio(2), 11, uO, uY, uM);
+    const int need = std::max(uO, std::max(uY, uM));
     if (need <= 1) return launchSeqAuto<1, 6, 2>(p, b, stream);
     if (need <= 2) return launchSeqAuto<2, 6, 2>(p, b, stream);
     if (need <= 3) return launchSeqAuto<3, 6, 2>(p, b, stream);
     if (need <= 4) return launchSeqAuto<4, 6, 2>(p, b, stream);
     if (need <= 6) return launchSeqAuto<6, 6, 2>(p, b, stream);
     if (need <= 9) return launchSeq<9, 6, false, false, 2>(p, b, stream);
+    if (need <= 10) return launchSeq<10, 6, false, false, 2>(p, b, stream);
     return launchSeq<11, 6, false, false, 2>(p, b, stream);
   }
-  int uA, uB;
-  seqUnitSplit(n, 6, 1, seqBalanceRatio(1), 12, uA, uB);
-  const int need = uA > uB ? uA : uB;
+  int uO, uY, uM;
+  seqUnitsFor(n, 6, 1, seqBalanceRatio(1), 12, uO, uY, uM);
+  const int need = std::max(uO, std::max(uY, uM));
   if (need <= 1) return launchSeqAuto<1, 7>(p, b, stream);
   if (need <= 2) return launchSeqAuto<2, 7>(p, b, stream);
   if (need <= 3) return launchSeqAuto<3, 7>(p, b, stream);
