@@ -119,6 +119,11 @@
 #ifndef PTW_SEQ_BALANCE_ONE
 #define PTW_SEQ_BALANCE_ONE 100
 #endif
+// two-master kernels, large scenes: share of the younger wave of a worker pair in percent of an older
+// wave's (seqUnitSplitByPlace; 100 = equal shares, round 3's form)
+#ifndef PTW_SEQ_YOUNG_PERCENT
+#define PTW_SEQ_YOUNG_PERCENT 70
+#endif
 
 #if PTW_PROFILE_PHASES
 #define PTW_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
@@ -2970,6 +2975,8 @@ void seqUnitsFor(uint32_t ntri, int nA, int nB, int ratio, int cap, int &uO, int
   int uA, uB;
   seqUnitSplit(ntri, nA, nB, ratio, cap, uA, uB);
   uO = uY = uA, uM = uB;
+  // (two masters, nobody asked for a ratio: shares by the wave's place where that applies)
+  if (nA == 4 && nB == 2 && !std::getenv("PTW_SEQ_BALANCE")) (void)seqUnitSplitByPlace(ntri, PTW_SEQ_YOUNG_PERCENT, cap, uO, uY, uM);
   if (const char *v = std::getenv("PTW_SEQ_UNITS")) {
     int o = -1, y = -1, m = -1;
     if (std::sscanf(v, "%d,%d,%d", &o, &y, &m) == 3 && o >= 0 && y >= 0 && m >= 0 && o <= cap && y <= cap && m <= cap)
