@@ -115,7 +115,7 @@ def parse_args():
                     help="skip the full-frame comparison with the reference (rmse_vs_ref)")
     ap.add_argument("--parity-passes", type=int, default=None,
                     help="passes of the frame compared with the reference's own code on the host (0: all --spp "
-                         "passes; default 24 for the headline, the bounded windows of SIDE_PARITY for cfg3 / cfg4: "
+                         "passes; default 12 for the headline, the bounded windows of SIDE_PARITY for cfg3 / cfg4: "
                          "this box's containers get about six cores, on which all 256 passes take 15 minutes)")
     ap.add_argument("--parity-rows", type=int, default=0,
                     help="rows [0, N) of the frame in that comparison (0: the whole frame / the config's window)")
@@ -308,27 +308,38 @@ def reference_kind(ob, scene_name):
     return "port"
 
 
-def ref_passes(ob, scene_name, view, cam, params, passes, threads, want_words, on_pass=None, strict=False):
+def ref_passes(ob, scene_name, view, cam, params, passes, threads, want_words, on_pass=None, strict=False,
+               want_picks=False):
     """Runs the reference's pass loop (Scene.cpp:209-219) for the given pass indices on `threads` host
     threads (one pass per thread at a time, like the reference's std::async tasks) and hands every
-    pass to `on_pass(pass_index, radiance, words)` IN PASS ORDER.  oracle/_ref when present, else the
-    restatement (`strict`: the -ffp-contract=off build of either)."""
+    pass to `on_pass(pass_index, radiance, words[, picks])` IN PASS ORDER.  oracle/_ref when present, else
+    the restatement (`strict`: the -ffp-contract=off build of either).  `want_picks`: the per-sample pick
+    checksum as well - the reference's IntersectionRecord carries no primitive index, so that number
+    comes from the restatement (a second run of the pass when oracle/_ref supplies the rest; the two must
+    agree on every sample's word count)."""
     if reference_kind(ob, scene_name) == "reference":
         rs = ob.RefScene(view, lib=ob.ref if strict and ob.ref is not None else ob.ref_fast)
         desc = ob.cam_desc(**ob.SCENE_CAMERAS[scene_name])
 
         def one(k):
-            return k, rs.render_pass(desc, params, k, want_words=want_words)
+            rad, words = rs.render_pass(desc, params, k, want_words=want_words or want_picks)
+            if not want_picks:
+                return k, (rad, words)
+            _, pwords, picks = ob.oracle_render_pass_picks(view, cam, params, k)
+            assert np.array_equal(pwords, words), "oracle/_ref and the restatement disagree on a word count"
+            return k, (rad, words, picks)
     else:
         lib = ob.oracle if strict or ob.oracle_fast is None else ob.oracle_fast
 
         def one(k):
+            if want_picks:
+                return k, ob.oracle_render_pass_picks(view, cam, params, k, lib=lib)
             return k, ob.oracle_render_pass(view, cam, params, k, lib=lib)
 
     with ThreadPoolExecutor(max_workers=threads) as pool:  # ctypes calls release the GIL
-        for k, (rad, words) in pool.map(one, passes):      # map() yields in submission order
+        for k, res in pool.map(one, passes):               # map() yields in submission order
             if on_pass:
-                on_pass(k, rad, words)
+                on_pass(k, *res)
 
 
 def cpu_leg(pkg, ob, scene_name, threads, passes, frame):
@@ -346,12 +357,16 @@ def cpu_leg(pkg, ob, scene_name, threads, passes, frame):
             "sample": f"{scene_name} {frame}x{frame}, {passes} full-frame passes, {n} samples in {dt:.1f} s"}
 
 
-def parity_vs_reference(pkg, ob, ctx, cam, view, scene_name, w, h, total_spp, seed, passes, rows_end, threads):
+def parity_vs_reference(pkg, ob, ctx, cam, view, scene_name, w, h, total_spp, seed, passes, rows_end, threads,
+                        want_picks=False):
     """The metric's second half: renders rows [0, rows_end) of the w x h frame once more on the GPU
     with per-sample RNG word counts (rows_end == h: the whole frame), runs the reference's own code
     for the same passes on the host cores, and compares every pixel and every sample's word count.
     Under the sequential policy a prefix of the rows is exactly what the full render produces for
-    them, so a bounded comparison is still a comparison of the stated frame."""
+    them, so a bounded comparison is still a comparison of the stated frame.  `want_picks`: every
+    sample's pick checksum too (which primitive each ray hit: ptw_debug_options.d_picks against the
+    oracle's) - the worker-wave kernels of the side configurations, whose instantiation is the same with
+    and without it."""
     spp = total_spp if passes <= 0 else min(total_spp, passes)
     rows_end = min(rows_end, h)
     window = dict(row_begin=0, row_end=rows_end) if rows_end < h else {}
@@ -364,10 +379,11 @@ def parity_vs_reference(pkg, ob, ctx, cam, view, scene_name, w, h, total_spp, se
     # two-passes-per-workgroup form of the worker-wave kernels when there are more passes than CUs -
     # true of the timed render of cfg3 / cfg4, not of a parity render of a few passes: ask for it.
     cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    force_mm = total_spp > cus >= spp and view.num_triangles > 128 and "PTW_SEQ_MM" not in os.environ
-    if force_mm:
-        os.environ["PTW_SEQ_MM"] = "1"
+    force_mm = total_spp > cus >= spp and view.num_triangles > 128
+    picks = torch.zeros((spp, h, w), dtype=torch.int32, device="cuda") if want_picks else None
     try:
+        if force_mm or want_picks:   # (the library's explicit test hook: ptw_context_set_debug)
+            ctx.set_debug(seq_two_masters=1 if force_mm else -1, d_picks=picks.data_ptr() if want_picks else 0)
         ctx.enable_stats(True)
         ctx.stats(reset=True)
         ctx.render(cam, params, rgb.data_ptr(), cnt.data_ptr(), words.data_ptr(),
@@ -376,18 +392,19 @@ def parity_vs_reference(pkg, ob, ctx, cam, view, scene_name, w, h, total_spp, se
         parity_kernel = ctx.stats(reset=True).trace_kernel.decode()
         ctx.enable_stats(False)
     finally:
-        if force_mm:
-            del os.environ["PTW_SEQ_MM"]
+        ctx.set_debug()
     gpu_sum = rgb.cpu().numpy()[:rows_end]
     gpu_cnt = cnt.cpu().numpy().astype(np.uint32)[:rows_end]
 
     ref_sum = np.zeros((rows_end, w, 3))
-    stats = {"word_mismatch": 0, "words_total": 0, "where": []}
+    stats = {"word_mismatch": 0, "words_total": 0, "where": [], "pick_mismatch": 0}
 
-    def on_pass(k, rad, wd):   # pass order: output += pass (ArrayOutput.cpp:48-56)
+    def on_pass(k, rad, wd, pk=None):   # pass order: output += pass (ArrayOutput.cpp:48-56)
         np.add(ref_sum, rad[:rows_end], out=ref_sum)
         gw = words[k].cpu().numpy().astype(np.uint32)[:rows_end]
         wd = wd[:rows_end]
+        if pk is not None:
+            stats["pick_mismatch"] += int((picks[k].cpu().numpy().astype(np.uint32)[:rows_end] != pk[:rows_end]).sum())
         bad = np.argwhere(gw != wd)
         stats["word_mismatch"] += len(bad)
         for y, x in bad[:4]:
@@ -398,16 +415,18 @@ def parity_vs_reference(pkg, ob, ctx, cam, view, scene_name, w, h, total_spp, se
 
     kind = reference_kind(ob, scene_name)
     t0 = time.perf_counter()
-    ref_passes(ob, scene_name, view, cam, params, list(range(spp)), threads, True, on_pass)
+    ref_passes(ob, scene_name, view, cam, params, list(range(spp)), threads, True, on_pass, want_picks=want_picks)
     dt = time.perf_counter() - t0
-    del words
+    del words, picks
     mean_gpu = gpu_sum / np.maximum(gpu_cnt, 1)[..., None]
     mean_ref = ref_sum / float(spp)
     diff = mean_gpu - mean_ref
     rmse = np.sqrt(np.mean(diff * diff, axis=(0, 1)))
     identical = np.all(gpu_sum == ref_sum, axis=2)
     nsamp = int(w) * rows_end * spp
+    out_picks = {"picks_differ": stats["pick_mismatch"]} if want_picks else {}
     return {
+        **out_picks,
         "rmse_vs_ref": [float(x) for x in rmse],
         "max_abs_diff": float(np.max(np.abs(diff))),
         "pixels_bit_identical": int(identical.sum()), "pixels": int(w * rows_end),
@@ -445,7 +464,7 @@ def roofline_of(stats, ntri, nsph):
     }
 
 
-def side_config(pkg, ob, name, device, threads, want_parity):
+def side_config(pkg, ob, name, device, threads, want_parity, want_cpu=False, cpu_threads=6):
     """One BASELINE configuration other than the headline, measured ONCE in this run (a single
     timed render, inputs resident in HBM) with the same fields as the main line."""
     cfg = CONFIGS[name]
@@ -491,11 +510,17 @@ def side_config(pkg, ob, name, device, threads, want_parity):
     }
     if want_parity:
         par, leg = parity_vs_reference(pkg, ob, ctx, cam, view, cfg["scene"], w, h, spp, 1,
-                                       SIDE_PARITY[name]["passes"], SIDE_PARITY[name]["rows_end"], threads)
-        for k in ("rmse_vs_ref", "samples_word_count_differs", "samples", "parity_kernel", "parity_rows",
+                                       SIDE_PARITY[name]["passes"], SIDE_PARITY[name]["rows_end"], threads,
+                                       want_picks=True)
+        for k in ("rmse_vs_ref", "samples_word_count_differs", "picks_differ", "samples", "parity_kernel", "parity_rows",
                   "parity_passes", "pixels_bit_identical", "pixels"):
             out[k] = par[k]
     del rgb, cnt
+    if want_cpu:
+        # the reference's own code beside it, at SURVEY 8(d)'s sub-run sizes (the rate does not depend on
+        # the frame size): 6 threads x 2 passes each, as scripts/bench-6t-*.sh run the reference
+        out["cpu_baseline"] = cpu_leg(pkg, ob, cfg["scene"], cpu_threads, 2 * cpu_threads, CPU_SAMPLE_FRAME[cfg["scene"]])
+        out["vs_cpu_6t"] = out["value"] / out["cpu_baseline"]["value"]
     return out
 
 
@@ -640,7 +665,11 @@ def main():
                 "workload": f"{args.scene} {w}x{h} @ {shard.total_spp} spp, maxDepth 5, 4x4 first bounce, "
                             f"rng_policy={args.policy}"
                             + (f"; TIMED SUB-RUN: image rows [{args.rows.replace(':', ', ')}) of the {w}x{h} frame "
-                               f"({shard.rows}/{h} of its samples)" if args.rows else ""),
+                               f"({shard.rows}/{h} of its samples)" if args.rows else "")
+                            + ("; N > 1: value = the SEED-MATCHED policy with the passes sharded over the GPUs - a pass "
+                               "is one serial chain, <= 256 passes do not strong-scale; the tile-sharded number "
+                               "north_star means is value_tile_sharded"
+                               if world > 1 and policy == pkg.RNG_SEQUENTIAL and shard.scaling == "strong" else ""),
                 "scene": args.scene, "triangles": ntri, "spheres": nsph, "width": w, "height": h,
                 "total_spp": shard.total_spp, "spp_this_rank": int(shard.params.samples_per_pixel),
                 "rng_policy": args.policy, "parallelism": shard.parallelism,
@@ -748,9 +777,10 @@ def main():
                 passes = SIDE_PARITY[args.config]["passes"] if passes is None else passes
             if args.parity_rows > 0:
                 rows_end = min(h, args.parity_rows)
-            passes = 24 if passes is None else passes
+            passes = 12 if passes is None else passes
             parity, all_cores_leg = parity_vs_reference(pkg, ob, ctx, cam, view, args.scene, w, h, spp, args.seed,
-                                                        passes, rows_end, usable_cpus())
+                                                        passes, rows_end, usable_cpus(),
+                                                        want_picks=args.config in SIDE_PARITY)
             result.update(parity)
             legs.append(all_cores_leg)
         if not args.no_cpu_baseline:
@@ -771,7 +801,8 @@ def main():
                 return time.perf_counter() - PROCESS_T0 < SIDE_LEG_DEADLINE_S
             if not args.no_other_configs:   # BASELINE cfg3 / cfg4, once each, same run
                 result["other_configs"] = [
-                    side_config(pkg, ob, name, device, usable_cpus(), not args.no_parity) if in_time() else
+                    side_config(pkg, ob, name, device, usable_cpus(), not args.no_parity, not args.no_cpu_baseline,
+                                args.cpu_threads) if in_time() else
                     {"config": name, "value": None, "note": f"skipped after {SIDE_LEG_DEADLINE_S} s; run --config {name}"}
                     for name in ("cfg3", "cfg4")]
             if not args.no_strict:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PTW_ABI_VERSION 4
+#define PTW_ABI_VERSION 5
 
 typedef enum ptw_status {
   PTW_OK = 0,
@@ -211,6 +211,45 @@ int ptw_render(const ptw_scene_view *scene, const ptw_camera *camera,
                const ptw_render_params *params, double *rgb_sum, uint32_t *counts,
                ptw_progress_fn progress, void *user);
 
+/* ---- Tests and A/B measurements ONLY: the library's dispatch forced from outside ----------
+ * Which kernel instantiation a render runs is the dispatcher's decision (scene size, pass count,
+ * LDS budget).  The test-suite has to reach every instantiation of the shipped binary with small
+ * scenes, and a measurement sometimes wants the road not taken: this struct says so explicitly,
+ * per context (ptw_context_set_debug) or per call (ptw_render_options.debug) - the process
+ * environment of a host that loads this library is not read for any of it.  A production host
+ * never sets it.  ptw_debug_defaults() fills in "the dispatcher decides" for every field. */
+typedef struct ptw_debug_options {
+  int32_t seq_two_masters;      /* worker-wave kernels (scenes beyond 128 triangles), two passes per
+                                   workgroup: -1 the dispatcher's rule (more passes than CUs), 0 never,
+                                   1 always                                                           */
+  int32_t seq_pairing;          /* two-master kernels, a second (speculated) sub-sample chain per
+                                   master in every request: -1 the dispatcher's rule, 0 off, 1 on     */
+  int32_t seq_lds_tables;       /* shading tables: -1 in LDS when they fit, 0 in global memory        */
+  int32_t seq_small_kernel;     /* scenes of at most 64 triangles: -1 the dispatcher's rule, 0 the
+                                   plain single-wave kernel (LDS tables, LDS stack), 1 the register
+                                   variant, 2 the speculative four-wave kernel whatever the pass count */
+  int32_t seq_units[3];         /* worker-wave kernels: resident units of 64 triangles of an older /
+                                   younger / master-side worker wave; {0, 0, 0} = the library's split */
+  int32_t pix_samples_per_lane; /* lock-step PERPIXEL kernel's grid-stride depth; 0 = default (8)     */
+  int32_t pix_waves_per_simd;   /* persistent PERPIXEL kernel: 0 = default (4), 2, 3 or 4             */
+  int32_t gang_groups;          /* experiments build only: CUs per pass of traceSequentialGang
+                                   (0 never; 2, 4, 8 when they fit the device)                        */
+  int32_t fail_shard;           /* ptw_render_ex(num_devices > 1) failure injection, -1 = none:       */
+  int32_t fail_collective;      /*   shard that fails its set-up / its collective call / reports      */
+  int32_t silent_shard;         /*   success WITHOUT entering the collective (the watchdog ends it)   */
+  int32_t trace;                /* 1: ptw_context_calibrate prints its two timings to stderr          */
+  /* Pick checksum (parity instrumentation, PTW_RNG_SEQUENTIAL only): a DEVICE pointer to
+   * [pass][y][x] uint32 receiving, per sample, sum over the sample's intersect() calls r = 0, 1, ...
+   * in the reference's call order of (r + 1) * (combined primitive index + 1) mod 2^32, a miss
+   * counting 0 - combined index = position in Scene::intersect's scan order: spheres [0, nsph),
+   * then triangles nsph + k (src/dod/Scene.cpp:115-122).  With it a comparison can tell WHICH
+   * primitive every ray hit, where radiance and RNG word counts cannot (ce: every path ends on an
+   * emitter of diffuse 0 and every ray hits something).  oracle/ptw_oracle.c computes the same
+   * number.  NULL = off; PTW_ERR_UNSUPPORTED under PTW_RNG_PERPIXEL.                                */
+  void *d_picks;
+} ptw_debug_options;
+void ptw_debug_defaults(ptw_debug_options *out);
+
 /* The same call with everything the reference's driver does around it (src/main/main.cpp:
  * 326-366): ONE context and one scene upload for the whole render, `update` handed the running
  * framebuffer (see ptw_update_fn), and - with num_devices > 1 - the reference's decomposition
@@ -237,7 +276,8 @@ typedef struct ptw_render_options {
                                   2: the N-GPU code path itself - a host thread, context and stream
                                      per shard, the collective through the in-process loopback
                                      transport (ptw_comm_create_loopback)                        */
-  int32_t reserved[3];
+  int32_t reserved;
+  const ptw_debug_options *debug; /* tests / A-B runs only (see ptw_debug_options); NULL = none */
 } ptw_render_options;
 int ptw_render_ex(const ptw_scene_view *scene, const ptw_camera *camera,
                   const ptw_render_params *params, double *rgb_sum, uint32_t *counts,
@@ -272,6 +312,9 @@ int ptw_context_render(ptw_context *ctx, const ptw_camera *camera,
  * trial. */
 int ptw_context_calibrate(ptw_context *ctx, const ptw_camera *camera,
                           const ptw_render_params *params, void *hip_stream, int32_t *kernel_out);
+/* Tests / A-B runs only: the context's renders from now on follow `options` (copied; NULL restores
+ * the defaults).  See ptw_debug_options. */
+int ptw_context_set_debug(ptw_context *ctx, const ptw_debug_options *options);
 /* Per-kernel timing gathered with hipEvents on the launch stream when enabled. */
 typedef struct ptw_kernel_stats {
   uint64_t trace_launches;   /* launches of the radiance kernel since the last reset   */

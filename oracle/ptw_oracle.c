@@ -183,6 +183,12 @@ typedef struct rng_t {
   sfc32 sfc;
   uint64_t words; /* 32-bit words consumed so far */
   uint64_t rays;  /* intersect() calls (statistics only) */
+  /* Pick checksum of the current sample (parity instrumentation, include/ptw.h ptw_debug_options.d_picks):
+   * sum over the sample's intersect() calls r = 0, 1, ... of (r + 1) * (combined primitive index + 1),
+   * misses 0; combined index = position in Scene::intersect's scan: spheres, then triangles.  The
+   * reference's IntersectionRecord carries no index, so this lives in the restatement - whose picks
+   * are pinned to oracle/_ref through radiance and materials on every scene where those differ. */
+  uint32_t sample_rays, picks;
 } rng_t;
 
 static inline uint32_t rng_word(rng_t *r) {
@@ -239,6 +245,7 @@ typedef struct hit_t {
   int inside;
   v3 position, normal;
   uint32_t material;
+  uint32_t prim; /* combined primitive index (pick checksum only; never read by the radiance path) */
 } hit_t;
 
 /* Ray::positionAlong Ray.h:25-27: origin + direction * t */
@@ -283,6 +290,7 @@ static hit_t intersect_spheres(const ptw_scene_view *s, const ray_t *ray, double
   h.position = hitPosition;
   h.normal = normal;
   h.material = s->sph_material[nearestIndex];
+  h.prim = (uint32_t)nearestIndex;
   return h;
 }
 
@@ -336,6 +344,7 @@ static hit_t intersect_triangles(const ptw_scene_view *s, const ray_t *ray, doub
   h.position = ray_position_along(ray, currentNearestDist);
   h.normal = backfacing ? v3_neg(normal) : normal;
   h.material = s->tri_material[nIndex];
+  h.prim = s->num_spheres + (uint32_t)nIndex;
   return h;
 }
 
@@ -420,6 +429,8 @@ static v3 radiance(const ptw_scene_view *s, rng_t *rng, const ray_t *ray, int de
 
   rng->rays++;
   const hit_t hit = intersect(s, ray);
+  rng->sample_rays++;
+  if (hit.valid) rng->picks += rng->sample_rays * (hit.prim + 1u);
   if (!hit.valid) return v3_from(s->environment);
 
   const ptw_material *mat = &s->materials[hit.material];
@@ -533,7 +544,8 @@ void oracle_camera_ray(const ptw_camera *cam, int32_t px, int32_t py, uint32_t s
 /* ------------------------------------------------------------------------------------- */
 static int render_pass_impl(const ptw_scene_view *scene, const ptw_camera *camera,
                             const ptw_render_params *rp, int32_t pass_index,
-                            double *radiance_out, uint32_t *words_out, uint64_t *rays_out) {
+                            double *radiance_out, uint32_t *words_out, uint64_t *rays_out,
+                            uint32_t *picks_out) {
   const int width = rp->width, height = rp->height;
   if (width <= 0 || height <= 0) return PTW_ERR_INVALID;
   /* std::mt19937 rng(renderParams.seed + curSample++): int -> unsigned long -> mod 2^32 */
@@ -564,12 +576,14 @@ static int render_pass_impl(const ptw_scene_view *scene, const ptw_camera *camer
       const size_t pix = (size_t)x + (size_t)y * width;
       if (rp->rng_policy == PTW_RNG_PERPIXEL) sfc32_seed(&rng.sfc, pass_seed, (uint32_t)pix);
       const uint64_t w0 = rng.words;
+      rng.sample_rays = 0, rng.picks = 0;
       ray_t ray = camera_random_ray(camera, x, y, &rng);
       v3 c = radiance(scene, &rng, &ray, 0, rp);
       radiance_out[pix * 3 + 0] = c.x;
       radiance_out[pix * 3 + 1] = c.y;
       radiance_out[pix * 3 + 2] = c.z;
       if (words_out) words_out[pix] = (uint32_t)(rng.words - w0);
+      if (picks_out) picks_out[pix] = rng.picks;
     }
   }
   if (rays_out) *rays_out = rng.rays;
@@ -579,7 +593,12 @@ static int render_pass_impl(const ptw_scene_view *scene, const ptw_camera *camer
 int oracle_render_pass(const ptw_scene_view *scene, const ptw_camera *camera,
                        const ptw_render_params *params, int32_t pass_index,
                        double *radiance_out, uint32_t *words_out) {
-  return render_pass_impl(scene, camera, params, pass_index, radiance_out, words_out, NULL);
+  return render_pass_impl(scene, camera, params, pass_index, radiance_out, words_out, NULL, NULL);
+}
+int oracle_render_pass_picks(const ptw_scene_view *scene, const ptw_camera *camera,
+                             const ptw_render_params *params, int32_t pass_index,
+                             double *radiance_out, uint32_t *words_out, uint32_t *picks_out) {
+  return render_pass_impl(scene, camera, params, pass_index, radiance_out, words_out, NULL, picks_out);
 }
 
 typedef struct job_t {
@@ -588,6 +607,7 @@ typedef struct job_t {
   const ptw_render_params *rp;
   double **pass_buffers; /* [spp] each width*height*3, allocated by the worker */
   uint32_t *words_out;
+  uint32_t *picks_out;
   int next_pass;
   uint64_t rays;
   int failed;
@@ -606,7 +626,7 @@ static void *worker_main(void *arg) {
     uint64_t rays = 0;
     int rc = buf ? render_pass_impl(job->scene, job->camera, job->rp, pass, buf,
                                     job->words_out ? job->words_out + npix * (size_t)pass : NULL,
-                                    &rays)
+                                    &rays, job->picks_out ? job->picks_out + npix * (size_t)pass : NULL)
                  : PTW_ERR_INVALID;
     pthread_mutex_lock(&job->lock);
     job->pass_buffers[pass] = buf;
@@ -620,6 +640,12 @@ static void *worker_main(void *arg) {
 int oracle_render(const ptw_scene_view *scene, const ptw_camera *camera,
                   const ptw_render_params *params, int32_t threads, double *rgb_sum,
                   uint32_t *counts, uint32_t *words_out, uint64_t *rays_out) {
+  return oracle_render_picks(scene, camera, params, threads, rgb_sum, counts, words_out, rays_out, NULL);
+}
+
+int oracle_render_picks(const ptw_scene_view *scene, const ptw_camera *camera,
+                        const ptw_render_params *params, int32_t threads, double *rgb_sum,
+                        uint32_t *counts, uint32_t *words_out, uint64_t *rays_out, uint32_t *picks_out) {
   if (!scene || !camera || !params || !rgb_sum || !counts) return PTW_ERR_INVALID;
   const int spp = params->samples_per_pixel;
   if (spp < 0 || params->width <= 0 || params->height <= 0) return PTW_ERR_INVALID;
@@ -632,6 +658,7 @@ int oracle_render(const ptw_scene_view *scene, const ptw_camera *camera,
   job.camera = camera;
   job.rp = params;
   job.words_out = words_out;
+  job.picks_out = picks_out;
   job.pass_buffers = (double **)calloc((size_t)(spp > 0 ? spp : 1), sizeof(double *));
   pthread_mutex_init(&job.lock, NULL);
   pthread_t *tids = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));

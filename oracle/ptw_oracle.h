@@ -57,12 +57,24 @@ int oracle_render_pass(const ptw_scene_view *scene, const ptw_camera *camera,
                        const ptw_render_params *params, int32_t pass_index,
                        double *radiance_out, uint32_t *words_out);
 
+/* The same with the per-pixel pick checksum of the pass (picks_out, width*height uint32, may be NULL):
+ * sum over a sample's intersect() calls r = 0, 1, ... of (r + 1) * (combined primitive index + 1) mod
+ * 2^32, a miss counting 0 (include/ptw.h, ptw_debug_options.d_picks). */
+int oracle_render_pass_picks(const ptw_scene_view *scene, const ptw_camera *camera,
+                             const ptw_render_params *params, int32_t pass_index,
+                             double *radiance_out, uint32_t *words_out, uint32_t *picks_out);
+
 /* All passes, merged in pass order into rgb_sum/counts (+=), `threads` worker threads
  * (one full-frame pass per thread at a time, as the reference).  words_out (may be NULL) is
  * [pass][y][x].  rays_out (may be NULL) receives the number of intersect() calls made. */
 int oracle_render(const ptw_scene_view *scene, const ptw_camera *camera,
                   const ptw_render_params *params, int32_t threads, double *rgb_sum,
                   uint32_t *counts, uint32_t *words_out, uint64_t *rays_out);
+
+/* ... and picks_out (may be NULL) [pass][y][x]. */
+int oracle_render_picks(const ptw_scene_view *scene, const ptw_camera *camera,
+                        const ptw_render_params *params, int32_t threads, double *rgb_sum,
+                        uint32_t *counts, uint32_t *words_out, uint64_t *rays_out, uint32_t *picks_out);
 
 /* ArrayOutput::pixelAt component conversion (src/util/ArrayOutput.cpp:9-12). */
 uint8_t oracle_component_to_int(double x);

@@ -117,12 +117,22 @@ UPDATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
 COMM_ID_BYTES = 128
 
 
+class DebugOptions(C.Structure):
+    """ptw_debug_options (include/ptw.h): TESTS AND A/B RUNS ONLY - the dispatcher's decisions forced
+    from outside, failure injection, the pick checksum buffer.  `debug_options()` fills the defaults."""
+    _fields_ = [("seq_two_masters", C.c_int32), ("seq_pairing", C.c_int32), ("seq_lds_tables", C.c_int32),
+                ("seq_small_kernel", C.c_int32), ("seq_units", C.c_int32 * 3),
+                ("pix_samples_per_lane", C.c_int32), ("pix_waves_per_simd", C.c_int32),
+                ("gang_groups", C.c_int32), ("fail_shard", C.c_int32), ("fail_collective", C.c_int32),
+                ("silent_shard", C.c_int32), ("trace", C.c_int32), ("d_picks", C.c_void_p)]
+
+
 class RenderOptions(C.Structure):
     """ptw_render_options (include/ptw.h): multi-device sharding and callbacks of ptw_render_ex."""
     _fields_ = [("num_devices", C.c_int32), ("min_updates", C.c_int32),
                 ("devices", C.POINTER(C.c_int32)), ("progress", PROGRESS_FN),
                 ("progress_user", C.c_void_p), ("update", UPDATE_FN), ("update_user", C.c_void_p),
-                ("share_device", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("share_device", C.c_int32), ("reserved", C.c_int32), ("debug", C.POINTER(DebugOptions))]
 
 _D3 = C.POINTER(C.c_double)
 
@@ -139,6 +149,7 @@ _sig("ptw_last_error", C.c_char_p)
 _sig("ptw_abi_version", C.c_int)
 _sig("ptw_default_params", None, C.POINTER(RenderParams))
 _sig("ptw_default_material", None, C.POINTER(Material))
+_sig("ptw_debug_defaults", None, C.POINTER(DebugOptions))
 _sig("ptw_material_diffuse", None, _D3, C.POINTER(Material))
 _sig("ptw_material_specular", None, _D3, C.c_double, C.POINTER(Material))
 _sig("ptw_material_light", None, _D3, C.POINTER(Material))
@@ -179,6 +190,7 @@ _sig("ptw_context_render", C.c_int, C.c_void_p, C.POINTER(Camera), C.POINTER(Ren
      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 _sig("ptw_context_calibrate", C.c_int, C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p,
      C.POINTER(C.c_int32))
+_sig("ptw_context_set_debug", C.c_int, C.c_void_p, C.POINTER(DebugOptions))
 _sig("ptw_context_enable_stats", C.c_int, C.c_void_p, C.c_int32)
 _sig("ptw_context_get_stats", C.c_int, C.c_void_p, C.POINTER(KernelStats), C.c_int32)
 _sig("ptw_context_intersect", C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
@@ -210,6 +222,22 @@ def default_params(**overrides) -> RenderParams:
             raise AttributeError(k)
         setattr(p, k, v)
     return p
+
+
+def debug_options(**overrides) -> DebugOptions:
+    """ptw_debug_defaults + overrides (`seq_units=(older, younger, master)`)."""
+    d = DebugOptions()
+    lib.ptw_debug_defaults(C.byref(d))
+    for k, v in overrides.items():
+        if not hasattr(d, k):
+            raise AttributeError(k)
+        if k == "seq_units":
+            d.seq_units[:] = [int(x) for x in v]
+        elif k == "d_picks":
+            d.d_picks = C.c_void_p(int(v) if v else None)
+        else:
+            setattr(d, k, int(v))
+    return d
 
 
 def material(kind: str = "default", colour=(0, 0, 0), *args) -> Material:
@@ -308,7 +336,7 @@ class Scene:
 
 
 def render(scene: Scene, camera: Camera, params: RenderParams, rgb_sum=None, counts=None,
-           progress=None, update=None, num_devices=0, share_device=False, min_updates=0):
+           progress=None, update=None, num_devices=0, share_device=False, min_updates=0, debug=None):
     """dod::Scene::render through ptw_render / ptw_render_ex (host buffers in and out).
 
     `progress(done, total)` and `update(done, total, rgb_sum, counts)` mirror the reference's
@@ -323,7 +351,7 @@ def render(scene: Scene, camera: Camera, params: RenderParams, rgb_sum=None, cou
     assert counts.dtype == np.uint32 and counts.size == n and counts.flags.c_contiguous
     cb = PROGRESS_FN(lambda user, done, total: int(bool(progress(done, total)))) if progress else None
     view = scene.view()
-    if update is None and num_devices <= 1:
+    if update is None and num_devices <= 1 and debug is None:
         _check(lib.ptw_render(C.byref(view), C.byref(camera), C.byref(params),
                               rgb_sum.ctypes.data, counts.ctypes.data,
                               C.cast(cb, C.c_void_p) if cb else None, None))
@@ -332,6 +360,8 @@ def render(scene: Scene, camera: Camera, params: RenderParams, rgb_sum=None, cou
     opt.num_devices = int(num_devices)
     opt.share_device = int(share_device)  # 0 | 1 (True): shards one after another | 2: threads + loopback collective
     opt.min_updates = int(min_updates)
+    if debug is not None:  # a DebugOptions (tests / A-B runs)
+        opt.debug = C.pointer(debug)
     if cb:
         opt.progress = cb
     ucb = None
@@ -424,6 +454,13 @@ class Context:
                                       C.c_void_p(d_rgb_sum), C.c_void_p(d_counts),
                                       C.c_void_p(d_words) if d_words else None,
                                       C.c_void_p(stream) if stream else None))
+
+    def set_debug(self, debug: "DebugOptions | None" = None, **overrides):
+        """Tests / A-B runs only (ptw_context_set_debug): `debug` or debug_options(**overrides); no
+        arguments restore the defaults."""
+        if debug is None and overrides:
+            debug = debug_options(**overrides)
+        _check(lib.ptw_context_set_debug(self._h, C.byref(debug) if debug is not None else None))
 
     def calibrate(self, camera: Camera, params: RenderParams, stream: int = 0) -> int:
         """PERPIXEL: times the policy's two kernels on this scene + frame shape (blocks), remembers

@@ -66,6 +66,13 @@ extern "C" {
 const char *ptw_last_error(void) { return g_lastError.c_str(); }
 int ptw_abi_version(void) { return PTW_ABI_VERSION; }
 
+void ptw_debug_defaults(ptw_debug_options *out) {
+  if (!out) return;
+  std::memset(out, 0, sizeof *out);
+  out->seq_two_masters = out->seq_pairing = out->seq_lds_tables = out->seq_small_kernel = -1;
+  out->fail_shard = out->fail_collective = out->silent_shard = -1;
+}
+
 void ptw_default_params(ptw_render_params *out) {
   if (!out) return;
   std::memset(out, 0, sizeof *out);

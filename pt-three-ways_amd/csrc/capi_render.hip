@@ -103,6 +103,9 @@ struct ptw_context {
   char traceKernel[64] = ""; // variant name of the last trace launch (a copy: the launcher's
                              // string lives in thread-local storage of the launching thread)
 
+  // tests / A-B runs only (ptw_context_set_debug): what the launchers are asked to do differently
+  ptw_debug_options debug;
+
   bool statsEnabled = false;
   struct Timed {
     hipEvent_t begin, end;
@@ -118,6 +121,16 @@ struct ptw_context {
   // of the budget to the free memory is divided among them
   int deviceShare = 1;
 
+  ptw_context() { ptw_debug_defaults(&debug); }
+  LaunchHints hints() const {
+    LaunchHints h;
+    h.seqTwoMasters = debug.seq_two_masters, h.seqPairing = debug.seq_pairing;
+    h.seqLdsTables = debug.seq_lds_tables, h.seqSmallKernel = debug.seq_small_kernel;
+    for (int i = 0; i < 3; ++i) h.seqUnits[i] = debug.seq_units[i];
+    h.pixSamplesPerLane = debug.pix_samples_per_lane, h.pixWavesPerSimd = debug.pix_waves_per_simd;
+    h.gangGroups = debug.gang_groups;
+    return h;
+  }
   void activate() const { check(hipSetDevice(device), "hipSetDevice"); }
   // Reads back and zeroes the per-pass ray counters (synchronous).
   uint64_t drainRays() {
@@ -238,7 +251,9 @@ TraceParams makeTraceParams(const ptw_context &ctx, const ptw_camera &cam,
   t.rowFirst = 0;
   t.rowStride = 1;
   t.accel = p.accel;
-  if (const char *v = std::getenv("PTW_PIX_COUNT_SLOTS")) t.padA = v[0] == '1'; // (read by the prof build only)
+#if defined(PTW_PROFILE_PHASES) && PTW_PROFILE_PHASES
+  if (const char *v = std::getenv("PTW_PIX_COUNT_SLOTS")) t.padA = v[0] == '1'; // (the prof build's lane-slot counter)
+#endif
   return t;
 }
 
@@ -292,6 +307,7 @@ int calibratePixKernel(ptw_context &ctx, const TraceParams &t, const TraceBuffer
   TraceBuffers bb = b;
   bb.rays = nullptr;  // the trial is not part of the render's statistics
   bb.words = nullptr;
+  const LaunchHints hints = ctx.hints();
   hipEvent_t ev[3];
   for (auto &e : ev) check(hipEventCreate(&e), "hipEventCreate");
   float ms[2] = {0, 0};
@@ -301,10 +317,10 @@ int calibratePixKernel(ptw_context &ctx, const TraceParams &t, const TraceBuffer
       if (warm) run.pixCount = std::min<uint32_t>(run.pixCount, 256), run.npass = 1;
       check(hipEventRecord(ev[0], stream), "hipEventRecord");
       run.pixKernel = kPixKernelLockstep;
-      check(launchTracePerPixel(run, bb, stream), "trial launch");
+      check(launchTracePerPixel(run, bb, hints, stream), "trial launch");
       check(hipEventRecord(ev[1], stream), "hipEventRecord");
       run.pixKernel = kPixKernelPersistent;
-      check(launchTracePerPixel(run, bb, stream), "trial launch");
+      check(launchTracePerPixel(run, bb, hints, stream), "trial launch");
       check(hipEventRecord(ev[2], stream), "hipEventRecord");
     }
     check(hipEventSynchronize(ev[2]), "hipEventSynchronize");
@@ -317,7 +333,7 @@ int calibratePixKernel(ptw_context &ctx, const TraceParams &t, const TraceBuffer
   for (auto &e : ev) (void)hipEventDestroy(e);
   ctx.pixChoiceKey = pixChoiceKeyOf(ctx, t, rows);
   ctx.pixChoice = ms[0] < ms[1] ? kPixKernelLockstep : kPixKernelPersistent;
-  if (std::getenv("PTW_PIX_TRACE"))
+  if (ctx.debug.trace)
     std::fprintf(stderr, "ptw: PERPIXEL trial (%u pixels x %u passes): lock-step %.3f ms, persistent %.3f ms -> %s\n",
                  tt.pixCount, tt.npass, ms[0], ms[1], ctx.pixChoice == kPixKernelLockstep ? "lock-step" : "persistent");
   return ctx.pixChoice;
@@ -367,8 +383,13 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   // speculation candidates per band from the statistics of
   // the band before: give it a short first band to measure on and at least eight bands, so that
   // the set follows the image from top to bottom.
+  const LaunchHints hints = ctx.hints();
+  if (ctx.debug.d_picks && !sequential)
+    throw DeviceError(PTW_ERR_UNSUPPORTED, "the pick checksum (ptw_debug_options.d_picks) needs PTW_RNG_SEQUENTIAL");
   TraceParams shape = t; // (what the dispatcher looks at: scene size, depth, pass count)
-  bool adaptive = sequential && pixTotal >= 16384 && seqGangGroups(shape) > 0;
+  bool adaptive = sequential && pixTotal >= 16384 && seqGangGroups(shape, hints) > 0;
+  if (adaptive && ctx.debug.d_picks)
+    throw DeviceError(PTW_ERR_UNSUPPORTED, "traceSequentialGang (experiments build) has no pick checksum");
   if (adaptive) bandPix = std::min<uint64_t>(bandPix, (pixTotal + 7) / 8);
   // equal bands (the last one is not a sliver)
   const uint64_t nBands = (pixTotal + bandPix - 1) / bandPix;
@@ -410,6 +431,7 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   b.mtPos = ctx.mtPos.ptr;
   b.stage = ctx.stage.ptr;
   b.words = dWords;
+  b.picks = sequential ? static_cast<uint32_t *>(ctx.debug.d_picks) : nullptr;
   b.rays = ctx.rays.ptr;
   ctx.sampleQueue.reserve(1);
   b.sampleQueue = ctx.sampleQueue.ptr;
@@ -461,9 +483,9 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
     t.firstBand = t.pixBegin == 0;
     const char *variant = "";
     if (sequential)
-      timedLaunch(true, [&] { return launchTraceSequential(t, b, stream, &variant); });
+      timedLaunch(true, [&] { return launchTraceSequential(t, b, hints, stream, &variant); });
     else
-      timedLaunch(true, [&] { return launchTracePerPixel(t, b, stream, &variant); });
+      timedLaunch(true, [&] { return launchTracePerPixel(t, b, hints, stream, &variant); });
     std::snprintf(ctx.traceKernel, sizeof ctx.traceKernel, "%s", variant ? variant : "");
     timedLaunch(false, [&] { return launchResolve(t, ctx.stage.ptr, dRgb, dCounts, stream); });
     done += static_cast<uint64_t>(t.pixCount) * npass;
@@ -561,6 +583,15 @@ int ptw_context_calibrate(ptw_context *ctx, const ptw_camera *camera, const ptw_
   if (kernel_out) *kernel_out = choice;
   return PTW_OK;
   PTW_GUARD_END
+}
+
+int ptw_context_set_debug(ptw_context *ctx, const ptw_debug_options *options) {
+  if (!ctx) return invalid("ctx");
+  if (options)
+    ctx->debug = *options;
+  else
+    ptw_debug_defaults(&ctx->debug);
+  return PTW_OK;
 }
 
 int ptw_context_enable_stats(ptw_context *ctx, int32_t enable) {
@@ -672,7 +703,6 @@ namespace {
 bool wantsCalibration(const ptw_render_params &p) {
   if (p.rng_policy != PTW_RNG_PERPIXEL || p.pix_kernel != PTW_PIX_KERNEL_AUTO || p.accel != PTW_ACCEL_NONE)
     return false;
-  if (std::getenv("PTW_PIX_KERNEL")) return false; // A/B override of the launcher
   const uint64_t samples = static_cast<uint64_t>(rowsOf(p).count) * static_cast<uint64_t>(p.width) *
                            static_cast<uint64_t>(std::max(0, p.samples_per_pixel));
   return samples >= kCalibrateFromSamples;
@@ -715,6 +745,7 @@ void renderSingle(const ptw_scene_view &scene, const ptw_camera &camera,
   if (ptw_context_create(params.device, &raw) != PTW_OK) throw DeviceError(PTW_ERR_NO_DEVICE, ptw_last_error());
   std::unique_ptr<ptw_context, void (*)(ptw_context *)> ctx(raw, ptw_context_destroy);
   if (int rc = ptw_context_set_scene(ctx.get(), &scene); rc != PTW_OK) throw DeviceError(rc, ptw_last_error());
+  if (opt.debug) ctx->debug = *opt.debug;
   const size_t npix = static_cast<size_t>(params.width) * params.height;
   DeviceArray<double> dRgb;
   DeviceArray<uint32_t> dCounts;
@@ -808,8 +839,16 @@ void renderMulti(const ptw_scene_view &scene, const ptw_camera &camera,
     if (ptw_context_create(sh.device, &raw) != PTW_OK) throw DeviceError(PTW_ERR_NO_DEVICE, ptw_last_error());
     sh.ctx.reset(raw);
     if (int rc = ptw_context_set_scene(sh.ctx.get(), &scene); rc != PTW_OK) throw DeviceError(rc, ptw_last_error());
+    if (opt.debug) sh.ctx->debug = *opt.debug;
     sh.rgb.upload(rgbSum, npix * 3, nullptr);
     sh.counts.upload(counts, npix, nullptr);
+    // one PERPIXEL kernel for every shard, measured once (as the threaded path does)
+    if (wantsCalibration(shards[0].params)) {
+      int32_t choice = PTW_PIX_KERNEL_AUTO;
+      if (int rc = ptw_context_calibrate(sh.ctx.get(), &camera, &shards[0].params, nullptr, &choice); rc != PTW_OK)
+        throw DeviceError(rc, ptw_last_error());
+      for (DeviceShard &each : shards) each.params.pix_kernel = choice;
+    }
     for (int g = 0; g < n; ++g) {
       enqueueRender(*sh.ctx, camera, shards[g].params, sh.rgb.ptr, sh.counts.ptr, nullptr, nullptr, 0,
                     [](const TraceParams &, uint64_t, uint64_t) { return false; });
@@ -839,16 +878,13 @@ void renderMulti(const ptw_scene_view &scene, const ptw_camera &camera,
     for (auto *c : comms) (void)ptw_comm_abort(c);
   };
   // Failure injection for the tests (a shard that fails must end the render with an error on every
-  // path, never leave its peers waiting in a collective): PTW_TEST_FAIL_SHARD=g fails shard g's
-  // set-up, PTW_TEST_FAIL_COLLECTIVE=g fails shard g's collective call.
-  auto envShard = [](const char *name) {
-    const char *v = std::getenv(name);
-    return v && *v ? std::atoi(v) : -1;
-  };
-  const int failSetup = envShard("PTW_TEST_FAIL_SHARD"), failCollective = envShard("PTW_TEST_FAIL_COLLECTIVE");
-  // PTW_TEST_SILENT_SHARD=g: shard g reports success WITHOUT entering the collective - the in-process
-  // picture of a peer that dies after the others have enqueued theirs; the watchdog must end it.
-  const int silentShard = envShard("PTW_TEST_SILENT_SHARD");
+  // path, never leave its peers waiting in a collective), ptw_debug_options: fail_shard = g fails shard
+  // g's set-up, fail_collective = g its collective call; silent_shard = g reports success WITHOUT entering
+  // the collective - the in-process picture of a peer that dies after the others have enqueued theirs;
+  // the watchdog must end it.
+  const int failSetup = opt.debug ? opt.debug->fail_shard : -1;
+  const int failCollective = opt.debug ? opt.debug->fail_collective : -1;
+  const int silentShard = opt.debug ? opt.debug->silent_shard : -1;
 
   // The PERPIXEL kernel choice is made ONCE, on the first shard's context, and handed to every
   // shard: all of them run the same kernel (two shards that each timed their own trial could pick
@@ -859,6 +895,7 @@ void renderMulti(const ptw_scene_view &scene, const ptw_camera &camera,
     sh.ctx.reset(raw);
     if (opt.share_device) raw->deviceShare = n;
     if (int rc = ptw_context_set_scene(sh.ctx.get(), &scene); rc != PTW_OK) throw DeviceError(rc, ptw_last_error());
+    if (opt.debug) raw->debug = *opt.debug;
   };
   if (wantsCalibration(shards[0].params) && failSetup != 0) {
     makeContext(shards[0]);
@@ -877,7 +914,7 @@ void renderMulti(const ptw_scene_view &scene, const ptw_camera &camera,
       threads.emplace_back([&, g] {
         DeviceShard &sh = shards[g];
         guarded(sh, [&] {
-          if (g == failSetup) throw DeviceError(PTW_ERR_HIP, "injected failure (PTW_TEST_FAIL_SHARD)");
+          if (g == failSetup) throw DeviceError(PTW_ERR_HIP, "injected failure (ptw_debug_options.fail_shard)");
           if (!sh.ctx) makeContext(sh);
           sh.ctx->activate();
           check(hipStreamCreateWithFlags(&sh.stream, hipStreamNonBlocking), "hipStreamCreate");
@@ -934,7 +971,7 @@ void renderMulti(const ptw_scene_view &scene, const ptw_camera &camera,
         int rc;
         if (g == failCollective) {
           rc = PTW_ERR_HIP;
-          sh.error = "injected failure (PTW_TEST_FAIL_COLLECTIVE)";
+          sh.error = "injected failure (ptw_debug_options.fail_collective)";
         } else if (g == silentShard) {
           return; // (test hook: this shard never shows up)
         } else {

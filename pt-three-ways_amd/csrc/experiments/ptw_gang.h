@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * kGangWaves) void traceSequentialGang(
   const int lane = threadIdx.x & 63;
   const bool leader = member == 0 && wave == 0; // stores the samples, keeps the statistics
 
-  using Ctx = SeqCtx<1, 1, true, true, true>;
+  using Ctx = SeqCtx<1, 1, true, true, true, 1, false, false>;
   Ctx ctx;
   ctx.triCompactGlobal = triCompact;
   ctx.matTableGlobal = matTable;
@@ -202,6 +202,8 @@ __global__ __launch_bounds__(64 * kGangWaves) void traceSequentialGang(
   ctx.words = 0;
   ctx.rays = 0;
   ctx.parity = 0;
+  ctx.picksOn = false; // (no pick checksum in this kernel: the dispatcher refuses d_picks for it)
+  ctx.pickReset();
   ctx.ringBase = ring;
   {
     SphereRec *ls = reinterpret_cast<SphereRec *>(ldsRaw + off);

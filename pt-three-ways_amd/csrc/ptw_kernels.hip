@@ -59,71 +59,20 @@
 #ifndef PTW_PROFILE_PHASES
 #define PTW_PROFILE_PHASES 0
 #endif
-// -DPTW_SEQ_SELECT=1: worker lanes with several resident triangles reject by select instead of by
-// branch (A/B switch)
-#ifndef PTW_SEQ_SELECT
-#define PTW_SEQ_SELECT 0
-#endif
-// -DPTW_EXPERIMENTS=1 (make experiments): also build the measured-slower opt-in kernels of
-// csrc/experiments/ (traceSequentialGang; the decoupled two-master protocol) and their env switches.
+// -DPTW_EXPERIMENTS=1 (make experiments): also build the measured-slower opt-in kernel of
+// csrc/experiments/ (traceSequentialGang) and its dispatch.
 #ifndef PTW_EXPERIMENTS
 #define PTW_EXPERIMENTS 0
-#endif
-// A/B switches of the worker-wave kernels' master path (make alt ALT_FLAGS="-DPTW_SEQ_PICK6=0 ..."):
-// the WAVES-way uniform pick over the workers' answers, and chainMaster().
-#ifndef PTW_SEQ_PICK6
-#define PTW_SEQ_PICK6 1
-#endif
-#ifndef PTW_SEQ_CHAIN_MASTER
-#define PTW_SEQ_CHAIN_MASTER 1
-#endif
-// Round 4 (make alt ALT_FLAGS="-DPTW_SEQ_PICK_MIN=0 -DPTW_SEQ_LDS_MIN=0" restores round 3's forms):
-//  PICK_MIN  the master's pick over the workers' answers as "minimum distance, then the lowest index
-//            among the answers that have it" (five v_min_f64, six compare-and-select, three v_min3_u32)
-//            instead of five lexicographic compare-and-select steps of ten instructions each;
-//  LDS_MIN   a worker wave whose lanes hold three or more candidates finds the nearest with ONE LDS
-//            atomic (ds_min_u64 on the distance's bit pattern, in a slot of its own) instead of two
-//            64-lane DPP reductions: the worker waves sit two to a SIMD, where every VALU instruction
-//            not issued is a slot for the other wave.
-#ifndef PTW_SEQ_PICK_MIN
-#define PTW_SEQ_PICK_MIN 1
-#endif
-#ifndef PTW_SEQ_LDS_MIN
-#define PTW_SEQ_LDS_MIN 1
-#endif
-// Two masters per workgroup: 0 = round 2's lock step, one barrier sequence for both masters (the
-// shipped form); 1 = the masters do not wait for each other - the workers poll both masters' request
-// words and answer whichever has a ray ready, no workgroup barrier on the ray path (round 4: built,
-// bit-identical, measured 3-15 % SLOWER - an LDS flag costs a polling round trip where s_barrier costs
-// 55 cycles; DESIGN.md 3.1.  In the experiments build, or make alt ALT_FLAGS=-DPTW_SEQ_DECOUPLED=1).
-#ifndef PTW_SEQ_DECOUPLED
-#define PTW_SEQ_DECOUPLED PTW_EXPERIMENTS // (measured slower than the lock step: DESIGN.md 3.1; experiments build only)
-#endif
-// s_sleep argument of the polling loops of the decoupled protocol (units of 64 cycles)
-#ifndef PTW_SEQ_POLL_SLEEP
-#define PTW_SEQ_POLL_SLEEP 1
-#endif
-// 1: whoever writes a request or an answer number then executes s_wakeup, which ends the s_sleep of
-// every wave of the workgroup that waits in a polling loop
-#ifndef PTW_SEQ_WAKEUP
-#define PTW_SEQ_WAKEUP 0
-#endif
-// default balance ratios of the worker-wave kernels (percent; seqUnitSplit)
-// (experiments build) traceSequentialGang by default when passes x 8 (or x 4) fit the CUs (0: only on PTW_SEQ_GANG=n)
-#ifndef PTW_SEQ_GANG_DEFAULT
-#define PTW_SEQ_GANG_DEFAULT 0
-#endif
-#ifndef PTW_SEQ_BALANCE_MM
-#define PTW_SEQ_BALANCE_MM 100
-#endif
-#ifndef PTW_SEQ_BALANCE_ONE
-#define PTW_SEQ_BALANCE_ONE 100
 #endif
 // two-master kernels, large scenes: share of the younger wave of a worker pair in percent of an older
 // wave's (seqUnitSplitByPlace; 100 = equal shares, round 3's form)
 #ifndef PTW_SEQ_YOUNG_PERCENT
 #define PTW_SEQ_YOUNG_PERCENT 70
 #endif
+// (Round 5 removed the A/B paths whose verdict is recorded in DESIGN.md 3.1 - rejection by select,
+// the lane-per-worker pick, radianceChain for the two-master path, the lexicographic pick, the DPP
+// reduction in the worker waves, the balance ratios by side, the decoupled two-master protocol and
+// its polling variants: last revision with all of them is commit 916a1dc.)
 
 #if PTW_PROFILE_PHASES
 #define PTW_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
@@ -347,7 +296,7 @@ struct SeqShared {
 
 // A worker wave's answer: its nearest hit.  16 bytes, one ds_read_b128 for the master: the distance
 // and the combined primitive index with the only fact ever used of the determinant - the sign test
-// `det < epsilon` of Scene.cpp:107 - in bit 31 (kMiss, all ones, with t = +inf for "nothing hit").
+// `det < epsilon` of Scene.cpp:107 - in bit 0 (kMiss, all ones, with t = +inf for "nothing hit").
 struct alignas(16) PartialHit {
   double t;
   uint32_t idxSign; // combined index << 1 | (det < epsilon); kMiss (all ones) with t = +inf for "nothing"
@@ -357,13 +306,12 @@ __device__ __forceinline__ uint32_t packAnswer(const HitKey &k) {
   return k.idx == kMiss ? kMiss : ((k.idx << 1) | (k.det < kEpsilon ? 1u : 0u));
 }
 // The nearest of n answers with the reference's tie-break (strictly nearer wins, an exact tie goes to
-// the lower combined index: Scene.cpp:31,95,118), computed by every lane alike - no cross-lane traffic.
+// the lower combined index: Scene.cpp:31,95,118), computed by every lane alike - no cross-lane traffic:
+// the minimum distance, then the lowest packed index among the answers that have it (the packing
+// keeps the order of the indices; a miss is +inf / all ones and loses against everything).
 template <int N>
 __device__ __forceinline__ HitKey pickOfAnswers(const PartialHit (&ph)[N]) {
   HitKey key;
-#if PTW_SEQ_PICK_MIN
-  // the minimum distance, then the lowest packed index among the answers that have it (the packing
-  // keeps the order of the indices; a miss is +inf / all ones and loses against everything)
   double bt = ph[0].t;
 #pragma unroll
   for (int w = 1; w < N; ++w) bt = vmin64(bt, ph[w].t);
@@ -373,36 +321,26 @@ __device__ __forceinline__ HitKey pickOfAnswers(const PartialHit (&ph)[N]) {
     const uint32_t c = ph[w].t == bt ? ph[w].idxSign : kMiss;
     bw = c < bw ? c : bw;
   }
-#else
-  double bt = ph[0].t;
-  uint32_t bw = ph[0].idxSign;
-#pragma unroll
-  for (int w = 1; w < N; ++w) {
-    const bool take = (ph[w].t < bt) | ((ph[w].t == bt) & (ph[w].idxSign < bw));
-    bt = take ? ph[w].t : bt;
-    bw = take ? ph[w].idxSign : bw;
-  }
-#endif
   key.t = bt;
   key.idx = bw == kMiss ? kMiss : (bw >> 1);
   key.det = (bw & 1u) ? -1.0 : 1.0; // (only its sign test is ever used)
   return key;
 }
-// Behind the answers: the masters' commands (64 bytes each: ray + request number), then - decoupled
-// protocol - one word per (master, worker): the request number the worker's answer belongs to.
-constexpr size_t kSeqCmdBytes = 256;
-constexpr size_t kSeqFlagsOffset = 128; // into the command area; [MASTERS][8] words
-constexpr size_t kSeqMinSlotOffset = 192; // ... then 8 bytes per worker wave (pickNearest's LDS atomic)
-constexpr uint32_t kSeqDone = 0xffffffffu; // request word of a master that has no more rays
+// Behind the answers: the masters' commands (128 bytes each: two rays + the request word), then 8 bytes
+// per worker wave and ray (pickNearest's LDS atomic).
+constexpr size_t kSeqCmdBytes = 384;
+constexpr size_t kSeqMinSlotOffset = 256; // into the command area; [8 waves][2 rays] x 8 bytes
 
-// Master -> worker request of the multi-wave sequential kernel.
+// Master -> worker request of the multi-wave sequential kernels: one ray, or - two-master kernels
+// with pairing - two (the second one belongs to the master's speculated chain, see PairMaster).
 constexpr uint32_t kCmdTrace = 1, kCmdExit = 2;
-constexpr uint32_t kCmdLive = 0xffffffffu; // traceSequentialMM: this master still has rays
-struct SeqCommand {
-  double o[3], d[3];
-  uint32_t op;   // lock-step protocols: see workerLoop; decoupled: the request number (0: none yet)
-  uint32_t pad;
-  uint32_t pad2[2]; // 64 bytes
+constexpr uint32_t kCmdLive = 0xffffffffu; // two masters: this master still has rays
+struct alignas(16) SeqCommand {
+  double o[3], d[3];   // ray A
+  double o2[3], d2[3]; // ray B (nrays == 2)
+  uint32_t op;         // one master: kCmdTrace / kCmdExit; two masters: see workerLoop
+  uint32_t nrays;      // two masters: rays in this request (1 or 2)
+  uint32_t pad[6];     // 128 bytes
 };
 
 // std::mt19937 regeneration (the "twist") + tempering + generate_canonical for all 312
@@ -446,15 +384,8 @@ struct SeqTables {
 // Layout of the per-lane shading record of the REG path (doubles).
 constexpr int kRecEmission = 0, kRecDiffuse = 3, kRecDoubles = 6;
 
-// Decoupled protocol: after the number that announces a request / an answer has been written, wake
-// the waves that sleep in their polling loops (the write has to have reached the LDS first).
-__device__ __forceinline__ void seqSignal() {
-#if PTW_SEQ_WAKEUP
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_wakeup" ::: "memory");
-#endif
-}
-
-template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false, bool SPEC = false, int MASTERS = 1>
+template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false, bool SPEC = false, int MASTERS = 1, bool PAIR = false,
+          bool PICKS = true>
 struct SeqCtx {
   // REG (single wave, one triangle per lane, at most 127 primitives, maxDepth <= 9): every lane
   // also keeps the emission and diffuse colour of its triangle in registers, and the (E, T)
@@ -482,7 +413,11 @@ struct SeqCtx {
   // master path is short of vector registers
   static constexpr bool kScalarConsts = MASTERS == 2;
   // two masters per workgroup: radiance0 and the chain use chainMaster / chainMasterFrom
-  static constexpr bool kMasterChain = PTW_SEQ_CHAIN_MASTER && WAVES > 1 && MASTERS == 2;
+  static constexpr bool kMasterChain = WAVES > 1 && MASTERS == 2;
+  // PAIR (two masters): every request carries up to two rays - the next ray of the sub-sample at the
+  // stream frontier and the next ray of the sub-sample AFTER it, started at a guessed stream position
+  // (pairPixel); the workers test their resident triangles against both.
+  static_assert(!PAIR || MASTERS == 2, "paired requests are a form of the two-master kernels");
   Surface laSurf;  // look-ahead inputs: the first-bounce surface, the incoming direction (set once per
   d3 laDir;        // pixel, before the fan-out: inside its loop they are the caller's own values), ...
   double laInvU, laInvV;
@@ -525,18 +460,17 @@ struct SeqCtx {
   SeqCommand *cmd;       // master -> workers (WAVES > 1); MASTERS == 2: this master's of allCmds[2]
   SeqCommand *allCmds;   // MASTERS == 2: both masters' commands
   unsigned tick;         // MASTERS == 2, lock step: workgroup barriers this wave has executed
-  // MASTERS == 2, decoupled protocol: the masters do not wait for each other.  A master publishes
-  // its ray and then the ray's request number (seq) in its command; a worker polls both masters'
-  // request words, searches whichever ray it has not answered yet, writes its answer and then, in
-  // flags[master][worker], the number of the request it belongs to; the master polls its six flags
-  // and reads the answers.  The LDS serves a wave's accesses in order, so "data first, number
-  // second" on the writing side and "number first, data second" on the reading side is all the
-  // ordering there is - no workgroup barrier on the ray path.
-  static constexpr bool kDecoupled = PTW_SEQ_DECOUPLED && MASTERS == 2;
-  unsigned long long *minSlot; // worker waves: this wave's 8 bytes of LDS for pickNearest's atomic form
-  uint32_t *flags;       // [MASTERS][8] in LDS
-  uint32_t seq;          // master: number of its current request (never 0, never kSeqDone)
+  unsigned long long *minSlot; // worker waves: this wave's 2 x 8 bytes of LDS for pickNearest's atomic form
   int masterIndex;
+  // Pick checksum (ptw_debug_options.d_picks): sum over the sample's intersect() calls r = 0, 1, ... of
+  // (r + 1) * (combined index + 1), misses 0.  pickS1 / pickS2 accumulate sum (idx + 1) and
+  // sum (i + 1) (idx + 1) over the calls since pickReset(); a segment that starts at call ordinal b
+  // contributes b * S1 + S2 (the speculative kernels commit whole sub-samples at once).
+  // PICKS = false compiles it out: the kernels whose wave has its SIMD to itself (WAVES == 1, the
+  // speculative kernel) pay an issue slot for every instruction, so their shipped instantiation carries
+  // none of this and a second one (launched when d_picks is set) does.
+  bool picksOn;
+  uint32_t pickS1, pickS2, pickN;
   int tid;               // index among the primitive-holding lanes (workers); master: lane id
   int pos;               // next canonical double in sh->canon (wave-uniform)
   d3 envColour;          // chainHot: the environment colour, kept in vector registers
@@ -759,7 +693,7 @@ struct SeqCtx {
       // profiles/r02r_pick_loop_probe.txt)
       unsigned tHi, tLo;
       double tmin;
-      if (PTW_SEQ_LDS_MIN && WAVES > 1 && slot) {
+      if (WAVES > 1 && slot) {
         // Distances are positive doubles: their bit patterns order like unsigned 64-bit integers.  The
         // first candidate lane resets the slot, every candidate lane folds its distance in with one
         // ds_min_u64, everybody reads the result - three LDS instructions of one wave to one address,
@@ -811,25 +745,6 @@ struct SeqCtx {
       // second loop exit the compiler stops unrolling from nine slots on, indexes the slot arrays
       // at run time and moves them to scratch memory)
       if (WAVES > 1 && s >= myUnits) continue;
-#if PTW_SEQ_SELECT
-      if (SLOTS > 1) { // several triangles per lane: rejection by select, no branch per test
-        const d3 v0 = mk(v0x[s], v0y[s], v0z[s]), e1 = mk(e1x[s], e1y[s], e1z[s]), e2 = mk(e2x[s], e2y[s], e2z[s]);
-        const d3 pVec = cross(d, e2);
-        const double det = dot(e1, pVec);
-        const double invDet = rcp(det);
-        const d3 tVec = o - v0;
-        const double u = dot(tVec, pVec) * invDet;
-        const d3 qVec = cross(tVec, e1);
-        const double v = dot(d, qVec) * invDet;
-        const double t = dot(e2, qVec) * invDet;
-        const bool reject = (__builtin_fabs(det) < kEpsilon) | (u < 0.0) | (u > 1.0) | (v < 0.0) | (u + v > 1);
-        const bool take = !reject & (t > kEpsilon) & (t < bestT);
-        bestT = take ? t : bestT;
-        bestIdx = take ? nsph + slotTriangle(s) : bestIdx;
-        bestDet = take ? det : bestDet;
-        continue;
-      }
-#endif
       testTriangle(o, d, mk(v0x[s], v0y[s], v0z[s]), mk(e1x[s], e1y[s], e1z[s]),
                    mk(e2x[s], e2y[s], e2z[s]), nsph + slotTriangle(s),
                    bestT, bestIdx, bestDet);
@@ -854,6 +769,53 @@ struct SeqCtx {
     PTW_T(tC);
     PTW_ACC(1, tB, tC);
     return key;
+  }
+
+  // The same for TWO rays at once (PAIR): every resident triangle is tested against both while its nine
+  // doubles sit in registers.  The rays are wave-uniform and arrive in scalar registers (every
+  // instruction of the test takes at most one of their components as its scalar operand), so a second
+  // ray costs the worker no vector registers beyond its own best-so-far triple.
+  __device__ __forceinline__ void localNearest2(d3 oA, d3 dA, d3 oB, d3 dB, HitKey &keyA, HitKey &keyB) {
+    PTW_T(tA);
+    double bestTA = kInf, bestDetA = 0, bestTB = kInf, bestDetB = 0;
+    uint32_t bestIdxA = kMiss, bestIdxB = kMiss;
+    const uint32_t nsph = p->nsph;
+    if (hasSphere) {
+      testSphere(oA, dA, mk(scx, scy, scz), sr2, static_cast<uint32_t>(tid), bestTA, bestIdxA);
+      testSphere(oB, dB, mk(scx, scy, scz), sr2, static_cast<uint32_t>(tid), bestTB, bestIdxB);
+    }
+    if (nsph > static_cast<uint32_t>(kThreads)) // rare: more spheres than lanes
+      for (uint32_t i = tid + kThreads; i < nsph; i += kThreads) {
+        const SphereRec &r = spheresGlobal[i];
+        testSphere(oA, dA, ld3(r.centre), r.radiusSquared, i, bestTA, bestIdxA);
+        testSphere(oB, dB, ld3(r.centre), r.radiusSquared, i, bestTB, bestIdxB);
+      }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      if (s >= myUnits) continue; // (a guard, not a break: see localNearest)
+      const d3 v0 = mk(v0x[s], v0y[s], v0z[s]), e1 = mk(e1x[s], e1y[s], e1z[s]), e2 = mk(e2x[s], e2y[s], e2z[s]);
+      testTriangle(oA, dA, v0, e1, e2, nsph + slotTriangle(s), bestTA, bestIdxA, bestDetA);
+      testTriangle(oB, dB, v0, e1, e2, nsph + slotTriangle(s), bestTB, bestIdxB, bestDetB);
+    }
+    if (p->ntri > residentTriangles()) // rare: more triangles than resident slots
+      for (uint32_t k = residentTriangles() + tid; k < p->ntri; k += kThreads) {
+        const double *g = triGeom + 9 * static_cast<size_t>(k);
+        const d3 v0 = ld3(g), e1 = ld3(g + 3), e2 = ld3(g + 6);
+        testTriangle(oA, dA, v0, e1, e2, nsph + k, bestTA, bestIdxA, bestDetA);
+        testTriangle(oB, dB, v0, e1, e2, nsph + k, bestTB, bestIdxB, bestDetB);
+      }
+#if PTW_PROFILE_PHASES
+    asm volatile("" : "+v"(bestTA), "+v"(bestTB));
+#endif
+    PTW_T(tB);
+    PTW_ACC(0, tA, tB);
+    keyA = pickNearest(bestTA, bestIdxA, bestDetA, minSlot);
+    keyB = pickNearest(bestTB, bestIdxB, bestDetB, minSlot + 1);
+#if PTW_PROFILE_PHASES
+    asm volatile("" : "+v"(keyA.t), "+v"(keyB.t));
+#endif
+    PTW_T(tC);
+    PTW_ACC(1, tB, tC);
   }
 
   __device__ __forceinline__ void setLookAheadFrame(const Surface &s, d3 dirIn, double invU, double invV) {
@@ -899,14 +861,24 @@ struct SeqCtx {
 
   // The nearest of the WAVES workers' answers with the reference's tie-break (strictly nearer wins,
   // an exact tie goes to the lower combined index: Scene.cpp:31,95,118).  Every lane of the master
-  // reads all answers (broadcast LDS reads, one wait) and runs the same WAVES - 1 compare-and-select
-  // steps: no cross-lane traffic at all, where the general pick spends 0.5-0.9 k cycles on ballots,
-  // readlanes and - from three candidates on - a 64-lane reduction.
-  __device__ __forceinline__ HitKey pickPartials() const {
+  // reads all answers (broadcast LDS reads, one wait) and runs the same pick: no cross-lane traffic at
+  // all, where the general pick spends 0.5-0.9 k cycles on ballots, readlanes and - from three
+  // candidates on - a 64-lane reduction.  PAIR: the answers of command slot `slot` (0 or 1).
+  __device__ __forceinline__ HitKey pickPartials(int slot = 0) const {
     PartialHit ph[WAVES];
+    const PartialHit *src = partials + slot * WAVES;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) ph[w] = partials[w];
+    for (int w = 0; w < WAVES; ++w) ph[w] = src[w];
     return pickOfAnswers(ph);
+  }
+
+  // Pick checksum bookkeeping (see picksOn).
+  __device__ __forceinline__ void pickReset() { pickS1 = 0, pickS2 = 0, pickN = 0; }
+  __device__ __forceinline__ void pickNote(const HitKey &k) {
+    const uint32_t v = k.idx == kMiss ? 0u : k.idx + 1u;
+    pickN += 1u;
+    pickS1 += v;
+    pickS2 += pickN * v;
   }
 
   // Scene::intersect for the whole workgroup.  WAVES == 1: the wave's own result.  WAVES > 1:
@@ -916,7 +888,11 @@ struct SeqCtx {
   // the waves of other passes.
   __device__ __forceinline__ HitKey intersect(d3 o, d3 d) {
     rays++;
-    if (WAVES == 1) return localNearest(o, d);
+    if (WAVES == 1) {
+      const HitKey key = localNearest(o, d);
+      if constexpr (PICKS) if (picksOn) pickNote(key);
+      return key;
+    }
     PTW_T(tM0);
 #if PTW_PROFILE_PHASES
     if (lastExit) {
@@ -930,63 +906,11 @@ struct SeqCtx {
       if (which == 5) g21 += gap, n21++;
     }
 #endif
-    if constexpr (kDecoupled) {
-      // ---- publish: the ray, then its number (same lane, so the LDS sees them in this order) ----
-      seq = seq + 1u;
-      if (seq == kSeqDone) seq = 1u; // (numbers are only ever compared for equality)
-      if ((threadIdx.x & 63) == 0) {
-        cmd->o[0] = o.x, cmd->o[1] = o.y, cmd->o[2] = o.z;
-        cmd->d[0] = d.x, cmd->d[1] = d.y, cmd->d[2] = d.z;
-        asm volatile("" ::: "memory");
-        *reinterpret_cast<volatile uint32_t *>(&cmd->op) = seq;
-      }
-      asm volatile("" ::: "memory");
-      seqSignal();
-#if PTW_PROFILE_PHASES
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-      PTW_T(tDa);
-      // the search takes a thousand cycles and more: the stack entry of the level just left and the
-      // next sub-sample's first-bounce scatter
-      flushPending();
-      if (laArmed) lookAhead();
-#if PTW_PROFILE_PHASES
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-      PTW_T(tDb);
-      // ---- wait for the six answers of THIS request: numbers first, answers second, one wait ----
-      typedef uint32_t U4 __attribute__((ext_vector_type(4)));
-      const volatile U4 *fl = reinterpret_cast<const volatile U4 *>(flags + masterIndex * 8);
-      PartialHit ph[WAVES];
-      for (;;) {
-        const U4 lo = fl[0], hi = fl[1]; // the eight numbers of this master: two ds_read_b128
-        const uint32_t got[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) ph[w] = partials[w];
-        asm volatile("" ::: "memory");
-        bool all = true;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) all = all && got[w] == seq;
-        if (uniformBool(all)) break;
-        __builtin_amdgcn_s_sleep(PTW_SEQ_POLL_SLEEP);
-      }
-      PTW_T(tDc);
-      HitKey key = pickOfAnswers(ph);
-#if PTW_PROFILE_PHASES
-      asm volatile("" : "+v"(key.t));
-      const unsigned long long tDd = __builtin_amdgcn_s_memtime();
-      mprof[0] += tDa - tM0, mprof[2] += tDb - tDa, mprof[3] += tDc - tDb, mprof[4] += tDd - tDc;
-      prof[5] += tDd - tM0;
-      lastKind = rayKind, lastMiss = key.idx == kMiss ? 1 : 0, lastExit = __builtin_amdgcn_s_memtime();
-      rayKind = 2;
-#endif
-      return key;
-    }
     if ((threadIdx.x & 63) == 0) { // (the master wave's first lane; cmd / partials are this master's)
       cmd->o[0] = o.x, cmd->o[1] = o.y, cmd->o[2] = o.z;
       cmd->d[0] = d.x, cmd->d[1] = d.y, cmd->d[2] = d.z;
       if (MASTERS == 1) cmd->op = kCmdTrace;
+      if (PAIR) cmd->nrays = 1u; // (mask of live command slots: slot 0 only)
     }
 #if PTW_PROFILE_PHASES
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -996,7 +920,7 @@ struct SeqCtx {
     PTW_T(tMb);
     // the search takes a thousand cycles and more: the stack entry of the level just left ...
     flushPending();
-    if (laArmed) lookAhead(); // ... and the next sub-sample's first-bounce scatter
+    if (!PAIR && laArmed) lookAhead(); // ... and the next sub-sample's first-bounce scatter
 #if PTW_PROFILE_PHASES
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -1009,18 +933,8 @@ struct SeqCtx {
     // (MASTERS == 2: the same two barriers - the workers search this ray between them, and the
     // other master's ray between B2 and this master's next B1, i.e. while this one shades)
     if (MASTERS == 2) tick += 2;
-#if PTW_SEQ_PICK6
     const HitKey key = pickPartials();
-#else
-    // lane w of the master takes worker w's result; the same pick as inside a wave finishes it
-    double ct = kInf, cdet = 0;
-    uint32_t cidx = kMiss;
-    if ((threadIdx.x & 63) < WAVES) {
-      const PartialHit ph = partials[threadIdx.x & 63];
-      ct = ph.t, cidx = ph.idxSign == kMiss ? kMiss : (ph.idxSign >> 1), cdet = (ph.idxSign & 1u) ? -1.0 : 1.0;
-    }
-    const HitKey key = pickNearest(ct, cidx, cdet);
-#endif
+    if constexpr (PICKS) if (picksOn) pickNote(key);
 #if PTW_PROFILE_PHASES
     asm volatile("" : "+v"(const_cast<HitKey &>(key).t));
 #endif
@@ -1034,56 +948,42 @@ struct SeqCtx {
     return key;
   }
 
+  // PAIR: one request for the rays that sit in this master's command slots (`mask`: bit c = slot c
+  // holds a ray; written by startChain / advance).  The answers are picked per slot by the caller.
+  // `shadow` runs between the two barriers, i.e. while the workers search.
+  template <typename Shadow>
+  __device__ __forceinline__ void searchSlots(uint32_t mask, Shadow &&shadow) {
+    if ((threadIdx.x & 63) == 0) cmd->nrays = mask;
+#if PTW_PROFILE_PHASES
+    PTW_T(tM0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    PTW_T(tMa);
+    ldsBarrier(); // B1
+    PTW_T(tMb);
+    shadow();
+#if PTW_PROFILE_PHASES
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    PTW_T(tMc);
+    ldsBarrier(); // B2
+    PTW_T(tMd);
+#if PTW_PROFILE_PHASES
+    mprof[0] += tMa - tM0, mprof[1] += tMb - tMa, mprof[2] += tMc - tMb, mprof[3] += tMd - tMc;
+    prof[5] += tMd - tM0;
+    mprof[5] += mask == 3u ? 1 : 0;
+#endif
+    tick += 2;
+  }
+
   // Worker waves (WAVES > 1, wave != 0): serve nearest-hit requests until told to stop.
   __device__ __forceinline__ void workerLoop() {
 #if PTW_PROFILE_PHASES
     for (int i = 0; i < 12; ++i) prof[i] = 0;
-    unsigned long long nreq = 0;
+    unsigned long long nreq = 0, nreq2 = 0;
     const unsigned long long w0 = __builtin_amdgcn_s_memtime();
 #endif
-    if constexpr (kDecoupled) {
-      // Poll both masters' request words; answer whichever has a request this wave has not answered
-      // yet (both: the one it did not serve last); leave when both masters are done.  Every poll
-      // reads the two numbers first and the two rays second, in one batch.
-      uint32_t served0 = 0, served1 = 0;
-      int prefer = 0;
-      const volatile uint32_t *op0 = &allCmds[0].op, *op1 = &allCmds[1].op;
-      for (;;) {
-        const uint32_t s0 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(*op0)));
-        const uint32_t s1 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(*op1)));
-        asm volatile("" ::: "memory");
-        const SeqCommand &c0 = allCmds[0], &c1 = allCmds[1];
-        const d3 o0 = mk(c0.o[0], c0.o[1], c0.o[2]), d0 = mk(c0.d[0], c0.d[1], c0.d[2]);
-        const d3 o1 = mk(c1.o[0], c1.o[1], c1.o[2]), d1 = mk(c1.d[0], c1.d[1], c1.d[2]);
-        asm volatile("" ::: "memory");
-        const bool new0 = s0 != served0 && s0 != kSeqDone && s0 != 0u;
-        const bool new1 = s1 != served1 && s1 != kSeqDone && s1 != 0u;
-        if (!(new0 | new1)) {
-          if (s0 == kSeqDone && s1 == kSeqDone) break;
-          __builtin_amdgcn_s_sleep(PTW_SEQ_POLL_SLEEP);
-          continue;
-        }
-        const int m = (new0 & new1) ? prefer : (new1 ? 1 : 0);
-        const d3 o = m ? o1 : o0, d = m ? d1 : d0;
-        const uint32_t sm = m ? s1 : s0;
-        const HitKey found = localNearest(o, d);
-        if ((tid & 63) == 0) {
-          PartialHit ph;
-          ph.t = found.t, ph.pad = 0;
-          ph.idxSign = packAnswer(found);
-          partials[m * WAVES + (tid >> 6)] = ph;
-          asm volatile("" ::: "memory");
-          *reinterpret_cast<volatile uint32_t *>(flags + m * 8 + (tid >> 6)) = sm;
-        }
-        asm volatile("" ::: "memory");
-        seqSignal();
-        if (m) served1 = sm; else served0 = sm;
-        prefer = m ^ 1;
-#if PTW_PROFILE_PHASES
-        nreq++;
-#endif
-      }
-    } else if (MASTERS == 2) {
+    if (MASTERS == 2) {
       // Barrier n is followed by the search of master (n & 1)'s ray, which that master published
       // before it.  A command's `op` holds the barrier index from which its master has no more
       // rays (kCmdLive while it has): a value that reads the same whenever it is looked at, so all
@@ -1096,14 +996,50 @@ struct SeqCtx {
           if (other <= n) break;
           continue;
         }
-        const d3 o = mk(c.o[0], c.o[1], c.o[2]);
-        const d3 d = mk(c.d[0], c.d[1], c.d[2]);
-        const HitKey found = localNearest(o, d);
-        if ((tid & 63) == 0) {
-          PartialHit ph;
-          ph.t = found.t, ph.pad = 0;
-          ph.idxSign = packAnswer(found);
-          partials[(n & 1) * WAVES + (tid >> 6)] = ph;
+        if constexpr (PAIR) {
+          // (wave-uniform: the mask of command slots that hold a ray)
+          const uint32_t mask = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(c.nrays)));
+          PartialHit *out = partials + (n & 1) * 2 * WAVES + (tid >> 6);
+          if (mask == 3u) {
+            // both rays into scalar registers: they are operands of every test of the search
+            const d3 oA = mk(readFirstLane(c.o[0]), readFirstLane(c.o[1]), readFirstLane(c.o[2]));
+            const d3 dA = mk(readFirstLane(c.d[0]), readFirstLane(c.d[1]), readFirstLane(c.d[2]));
+            const d3 oB = mk(readFirstLane(c.o2[0]), readFirstLane(c.o2[1]), readFirstLane(c.o2[2]));
+            const d3 dB = mk(readFirstLane(c.d2[0]), readFirstLane(c.d2[1]), readFirstLane(c.d2[2]));
+            HitKey fA, fB;
+            localNearest2(oA, dA, oB, dB, fA, fB);
+            if ((tid & 63) == 0) {
+              PartialHit ph;
+              ph.t = fA.t, ph.pad = 0, ph.idxSign = packAnswer(fA);
+              out[0] = ph;
+              ph.t = fB.t, ph.idxSign = packAnswer(fB);
+              out[WAVES] = ph;
+            }
+#if PTW_PROFILE_PHASES
+            nreq2++;
+#endif
+          } else {
+            const bool second = mask == 2u;
+            const double *ro = second ? c.o2 : c.o, *rd = second ? c.d2 : c.d;
+            const d3 o = mk(ro[0], ro[1], ro[2]);
+            const d3 d = mk(rd[0], rd[1], rd[2]);
+            const HitKey found = localNearest(o, d);
+            if ((tid & 63) == 0) {
+              PartialHit ph;
+              ph.t = found.t, ph.pad = 0, ph.idxSign = packAnswer(found);
+              out[second ? WAVES : 0] = ph;
+            }
+          }
+        } else {
+          const d3 o = mk(c.o[0], c.o[1], c.o[2]);
+          const d3 d = mk(c.d[0], c.d[1], c.d[2]);
+          const HitKey found = localNearest(o, d);
+          if ((tid & 63) == 0) {
+            PartialHit ph;
+            ph.t = found.t, ph.pad = 0;
+            ph.idxSign = packAnswer(found);
+            partials[(n & 1) * WAVES + (tid >> 6)] = ph;
+          }
         }
 #if PTW_PROFILE_PHASES
         nreq++;
@@ -1130,19 +1066,13 @@ struct SeqCtx {
 #if PTW_PROFILE_PHASES
     if (blockIdx.x == 0 && (tid & 63) == 0) { // every worker wave: which ones are the slow ones?
       const unsigned long long w1 = __builtin_amdgcn_s_memtime();
-      printf("WORKER rank=%d (hardware wave %d, %d units) requests=%llu total/req=%.0f tests=%.0f reduce=%.0f\n", tid >> 6,
-             (int)(threadIdx.x >> 6), myUnits, nreq, (double)(w1 - w0) / nreq, (double)prof[0] / nreq, (double)prof[1] / nreq);
+      printf("WORKER rank=%d (hardware wave %d, %d units) requests=%llu (two rays: %llu) total/req=%.0f tests=%.0f reduce=%.0f\n", tid >> 6,
+             (int)(threadIdx.x >> 6), myUnits, nreq, nreq2, (double)(w1 - w0) / nreq, (double)prof[0] / nreq, (double)prof[1] / nreq);
     }
 #endif
   }
   __device__ __forceinline__ void stopWorkers() {
     if (WAVES == 1) return;
-    if constexpr (kDecoupled) {
-      // (every request of this master has been answered: nothing of it is pending anywhere)
-      if ((threadIdx.x & 63) == 0) *reinterpret_cast<volatile uint32_t *>(&cmd->op) = kSeqDone;
-      seqSignal();
-      return;
-    }
     if (MASTERS == 2) {
       // no more rays from this master as of its next barrier; keep the cadence until the other
       // one is done too (see workerLoop)
@@ -1190,6 +1120,20 @@ struct SeqCtx {
     }
   }
 
+  // The same scatter with the three draws at block position q (q + 3 <= kMtDoubles), without touching
+  // the stream position: the frontier chain calls it through scatterChain(), a speculated chain (PAIR)
+  // with its own position.
+  __device__ __forceinline__ bool scatterChainAt(int q, const Surface &s, d3 dirIn, d3 &dirOut) const {
+    const double pd = sh->canon[q + 2];
+    const d3 local = mk(sh->hemi[q][0], sh->hemi[q][1], sh->hemi[q][2]);
+    if (uniformBool(lobeIsReflective(s, dirIn, pd))) { // Scene.cpp:163-168
+      dirOut = coneSample(reflect(s.normal, dirIn), s.coneAngle, sh->canon[q], sh->canon[q + 1]);
+      return true;
+    }
+    dirOut = normalisedNearUnit(transform(s.basis, local)); // Scene.cpp:169-175
+    return false;
+  }
+
   // The scatter of a single-sample level (depth >= 1): u = xi1, v = xi2, p = xi3 drawn in that
   // order (Scene.cpp:157-161).  When the three draws sit inside the current block, the diffuse
   // lobe takes its local direction from the precomputed table.
@@ -1209,16 +1153,9 @@ struct SeqCtx {
     }
     if (pos + 3 <= kMtDoubles) {
       const int q = pos;
-      const double pd = sh->canon[q + 2];
-      const d3 local = mk(sh->hemi[q][0], sh->hemi[q][1], sh->hemi[q][2]);
       pos += 3;
       words += 6;
-      if (uniformBool(lobeIsReflective(s, dirIn, pd))) { // Scene.cpp:163-168
-        dirOut = coneSample(reflect(s.normal, dirIn), s.coneAngle, sh->canon[q], sh->canon[q + 1]);
-        return true;
-      }
-      dirOut = normalisedNearUnit(transform(s.basis, local)); // Scene.cpp:169-175
-      return false;
+      return scatterChainAt(q, s, dirIn, dirOut);
     }
     double u, v, pd;
     draw3(u, v, pd); // straddles a regeneration
@@ -1294,11 +1231,9 @@ struct SeqCtx {
   __device__ __forceinline__ d3 runChain(const TraceParams &tp, const TriShade *ts, const SphereRec *sp,
                                          d3 o, d3 d) {
     if (REG) return chainHot(tp, o, d);
-#if PTW_SEQ_CHAIN_MASTER
     // (two masters: suzanne 512 passes +1 %, ce +6 %; with one master per workgroup it measured 5 %
     // slower than radianceChain - profiles/r03c_worker_wave_master_path.txt - and is not used there)
     if (WAVES > 1 && MASTERS == 2) return chainMaster(tp, o, d);
-#endif
     return radianceChain(*this, tp, ts, sp, o, d);
   }
 
@@ -1385,6 +1320,294 @@ struct SeqCtx {
     flushPending();
     for (int i = nlev - 1; i >= 0; --i) L = fold(i, L);
     return L;
+  }
+
+  // =========================================================================================
+  // PAIR (two-master kernels, round 5): TWO sub-samples of the first-bounce fan-out in flight per
+  // master.  The stream makes a pass serial but not unpredictable (see traceSequentialSpec): sub-sample
+  // j + 1 starts where j stops, and the number of draws j consumes - three per level it reaches - takes
+  // few values that repeat (suzanne: 3 in four cases of five; ce: always 15).  So next to the chain X of
+  // the sub-sample at the stream frontier the master keeps a chain Y for the sub-sample after it,
+  // started at the position X WOULD leave the stream at if it consumed g = max(m1, levels X has
+  // consumed already) levels, m1 being the most frequent count of this pass so far.  Every request to
+  // the workers carries the next ray of both (command slots 0 and 1; SeqCommand::nrays is the mask of
+  // slots that hold a ray) and comes back with two nearest hits: one barrier pair, one hand-off, one
+  // pick round for two rays - the worker waves, idle half of every tick on suzanne, test their
+  // resident triangles against both while they have them in registers.  When X ends, Y is the
+  // frontier's sub-sample if and only if it started where X stopped (Y.start == pos): then it is
+  // promoted - with whatever it has traced since - and a new Y is started behind it; otherwise it is
+  // dropped and costs nothing but the workers' time.  X's contribution is added when X ends, so the
+  // contributions are added in sub-sample order and the value is the one the serial evaluation defines,
+  // bit for bit; the RNG word count of a sample is the frontier's progress, the ray counter counts
+  // committed sub-samples only.  A chain's in-flight ray lives in its command slot, its (E, T) levels
+  // in its own LDS stack; what stays in registers is a dozen wave-uniform integers per chain.
+  // Y is only started where its worst case (3 maxDepth draws) ends inside the generator block, so a
+  // speculated chain never regenerates - and neither does X while a Y exists (X.start <= Y.start).
+  // =========================================================================================
+  struct Chain {
+    int slot;       // command slot, answers and stack of this chain (0 or 1)
+    int sub;        // sub-sample index
+    int start, pos; // Y: block position of its first / next draw (X draws at the frontier: ctx.pos)
+    int depth;      // depth of the ray in flight (1: the ray that leaves the first-bounce surface)
+    int levels;     // groups of three draws consumed so far (the scatter at the first-bounce surface = 1)
+    int nlev;       // levels on its stack
+    bool refl0;     // lobe taken at the first-bounce surface
+    bool live, done;
+    bool pend;      // the level `pendLevel` (a diffuse triangle bounce) still has to be written to the stack
+    int pendLevel;
+    uint32_t pendIdx;
+    uint32_t rays, s1, s2; // intersect() calls so far; pick checksum partial sums
+    d3 L;           // done: radiance(depth 1) of the sub-sample
+  };
+  int stackStride;         // levels per chain stack: chain c uses stack[c.slot * stackStride + level]
+  unsigned long long hist; // levels consumed by this pass's committed sub-samples (6-bit fields 1..9)
+  int m1;                  // the most frequent of them (refreshed once per pixel)
+
+  __device__ __forceinline__ void writeRay(int slot, d3 o, d3 d) {
+    if ((threadIdx.x & 63) == 0) {
+      double *po = slot ? cmd->o2 : cmd->o, *pd = slot ? cmd->d2 : cmd->d;
+      po[0] = o.x, po[1] = o.y, po[2] = o.z;
+      pd[0] = d.x, pd[1] = d.y, pd[2] = d.z;
+    }
+  }
+  __device__ __forceinline__ void readRay(int slot, d3 &o, d3 &d) const {
+    const double *po = slot ? cmd->o2 : cmd->o, *pd = slot ? cmd->d2 : cmd->d;
+    o = mk(po[0], po[1], po[2]);
+    d = mk(pd[0], pd[1], pd[2]);
+  }
+  __device__ __forceinline__ void chainPush(const Chain &c, int level, d3 e, d3 dif, bool refl) {
+    if ((threadIdx.x & 63) == 0) {
+      Level lv;
+      lv.emission = e;
+      lv.diffuse = dif;
+      lv.reflective = refl;
+      stack[c.slot * stackStride + level] = lv;
+    }
+  }
+  // (called while the workers search: the colours' fetch - triangle record -> material index ->
+  // material, dependent round trips - is off the serial path, as with flushPending())
+  __device__ __forceinline__ void chainFlush(Chain &c) {
+    if (!(c.live && c.pend)) return;
+    const double *r = tab.tri + static_cast<size_t>(c.pendIdx - p->nsph) * kTriCompactDoubles;
+    const double *m = tab.mat + static_cast<size_t>(static_cast<uint32_t>(r[kTriMaterialIndex])) * kMatDoubles;
+    chainPush(c, c.pendLevel, ld3(m), ld3(m + 3), false);
+    c.pend = false;
+  }
+  // The chain has ended with radiance `L` at its innermost level: fold its stack (Scene.cpp:163-175).
+  __device__ __forceinline__ void chainFinish(Chain &c, d3 L) {
+    chainFlush(c);
+    for (int i = c.nlev - 1; i >= 0; --i) {
+      const Level lv = stack[c.slot * stackStride + i];
+      L = uniformBool(lv.reflective) ? lv.emission + L : lv.emission + lv.diffuse * L;
+    }
+    c.L = L;
+    c.done = true;
+  }
+  // The answer `k` to the chain's ray in flight: radianceChain()'s / chainMasterFrom()'s level, once.
+  // IS_X: the frontier chain draws at ctx.pos (and may regenerate); a speculated chain at c.pos.
+  template <bool IS_X>
+  __device__ __forceinline__ void chainAdvance(Chain &c, const HitKey &k) {
+    const uint32_t pv = k.idx == kMiss ? 0u : k.idx + 1u;
+    c.rays += 1u;
+    c.s1 += pv;
+    c.s2 += c.rays * pv;
+    if (uniformBool(k.idx == kMiss)) { // Scene.cpp:131-133
+      chainFinish(c, envColour);
+      return;
+    }
+    if (c.depth + 1 >= p->maxDepth) { // last level: see radianceChain()
+      if (IS_X) skip3(); else c.pos += 3;
+      c.levels += 1;
+      chainFinish(c, emissionAt(k));
+      return;
+    }
+    d3 o, d;
+    readRay(c.slot, o, d);
+    const uint32_t nsph = p->nsph, ntri = p->ntri;
+    const int q = IS_X ? pos : c.pos;
+    const bool inBlock = IS_X ? q + 3 <= kMtDoubles : true;
+    const bool isTri = (k.idx - nsph) < ntri; // unsigned: spheres fail
+    bool handled = false;
+    if (isTri & inBlock) {
+      // the common level (chainMasterFrom): a triangle, the diffuse lobe decided from the record's lobe
+      // threshold as lane-mask logic, all LDS operands waited for once
+      const double *r = tab.tri + static_cast<size_t>(k.idx - nsph) * kTriCompactDoubles;
+      d3 n = ld3(r), bx = ld3(r + 3), by = ld3(r + 6);
+      double thr = r[kTriLobeThreshold];
+      double pd = sh->canon[q + 2];
+      const double *hm = sh->hemi[q];
+      d3 local = mk(hm[0], hm[1], hm[2]);
+      asm volatile("" : "+v"(n.x), "+v"(bx.x), "+v"(by.x), "+v"(thr), "+v"(pd), "+v"(local.x)); // one wait
+      const bool backfacing = k.det < kEpsilon; // Scene.cpp:107
+      const double ndotd = dot(n, d);
+      const double cosThetaI = backfacing ? ndotd : -ndotd;
+      const unsigned long long mNotRefl = __builtin_amdgcn_ballot_w64(!(pd < thr));
+      const unsigned long long mPlain = __builtin_amdgcn_ballot_w64(thr >= 0.0);
+      const unsigned long long mCos = __builtin_amdgcn_ballot_w64(cosThetaI >= 1e-3);
+      const unsigned long long mPos = __builtin_amdgcn_ballot_w64(pd > 0.0);
+      if ((mNotRefl & (mPlain | (mCos & mPos))) != 0) {
+        if (IS_X) pos += 3, words += 6; else c.pos += 3;
+        Basis b;
+        b.x = bx, b.y = by, b.z = n;
+        const double sgn = backfacing ? -1.0 : 1.0;
+        const d3 nd = normalisedNearUnit(transform(b, mk(local.x * sgn, local.y, local.z * sgn)));
+        writeRay(c.slot, o + d * k.t, nd);
+        c.pend = true, c.pendLevel = c.nlev, c.pendIdx = k.idx;
+        c.nlev += 1;
+        handled = true;
+      }
+    }
+    if (!handled) { // sphere, reflective lobe, Fresnel evaluation, draws straddling a regeneration
+      const Surface s = surfaceAt(k, o, d, false);
+      d3 nd;
+      bool refl;
+      if (IS_X) {
+        refl = scatterChain(s, d, nd);
+      } else {
+        refl = scatterChainAt(q, s, d, nd);
+        c.pos += 3;
+      }
+      chainPush(c, c.nlev, s.emission, s.diffuse, refl);
+      c.nlev += 1;
+      writeRay(c.slot, s.pos, nd);
+    }
+    c.depth += 1;
+    c.levels += 1;
+  }
+
+  // One request for the rays in this master's command slots (`mask`: bit c = slot c): publish + B1 ...
+  __device__ __forceinline__ void searchBegin(uint32_t mask) {
+    if ((threadIdx.x & 63) == 0) cmd->nrays = mask;
+#if PTW_PROFILE_PHASES
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (lastExit) mprof[0] += t0 - lastExit;
+    mprof[5] += mask == 3u ? 1 : 0;
+#endif
+    ldsBarrier(); // B1: the rays are visible to the workers
+#if PTW_PROFILE_PHASES
+    lastExit = __builtin_amdgcn_s_memtime();
+    mprof[1] += lastExit - t0;
+#endif
+  }
+  // ... (the caller's shadow work) ... B2: the answers are there.
+  __device__ __forceinline__ void searchEnd() {
+#if PTW_PROFILE_PHASES
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    mprof[2] += t0 - lastExit;
+#endif
+    ldsBarrier(); // B2
+#if PTW_PROFILE_PHASES
+    lastExit = __builtin_amdgcn_s_memtime();
+    mprof[3] += lastExit - t0;
+    prof[5] += 1;
+#endif
+    tick += 2;
+  }
+
+  // radiance(rng, ray, 0, renderParams) for the PAIR master: radiance0() with the fan-out traced as
+  // described above.  (maxDepth >= 2, at most 9: launchSeq dispatches the plain form otherwise.)
+  __device__ __forceinline__ d3 pairPixel(const TraceParams &tp, d3 o, d3 d) {
+    markRay(0);
+    const HitKey k0 = intersect(o, d);
+    if (uniformBool(k0.idx == kMiss)) return ld3(tp.env);
+    const Surface s0 = surfaceAt(k0, o, d);
+    if (tp.preview) return s0.diffuse; // Scene.cpp:137-138
+    d3 result = mk(0, 0, 0);
+    double invU = tp.invU, invV = tp.invV;
+    asm volatile("" : "+v"(invU), "+v"(invV));
+    const int nSub = tp.fbU * tp.fbV, fbV = tp.fbV;
+    const int vShift = fbV > 0 ? 31 - __builtin_clz(static_cast<unsigned>(fbV)) : 0;
+    const int maxDepth = tp.maxDepth;
+    { // the guess of this pixel: the most frequent number of levels so far (none yet: the depth cap)
+      int best = maxDepth, bestN = 0;
+#pragma unroll
+      for (int f = 1; f <= 9; ++f) {
+        const int n = static_cast<int>(hist >> (6 * f)) & 63;
+        const bool top = n > bestN;
+        best = top ? f : best;
+        bestN = top ? n : bestN;
+      }
+      m1 = best;
+    }
+    Chain X, Y;
+    X.live = false, Y.live = false;
+    X.done = false, Y.done = false;
+    X.pend = false, Y.pend = false;
+    int j = 0; // sub-samples committed
+    for (;;) {
+      // ---- refill: X at the frontier, Y behind it at the guessed position ----
+#pragma nounroll
+      for (int n = 0; n < 2; ++n) {
+        const bool forX = n == 0;
+        int sub, q;
+        if (forX) {
+          if (X.live | (j >= nSub)) continue;
+          sub = j, q = pos;
+        } else {
+          if (!X.live | Y.live | (X.sub + 1 >= nSub)) continue;
+          const int g = m1 > X.levels ? m1 : X.levels;
+          sub = X.sub + 1, q = pos + 3 * (g - X.levels);
+          if (q + 3 * maxDepth > kMtDoubles) continue; // a speculated chain never leaves the block
+        }
+        double xu, xv, pd;
+        if (forX) {
+          draw3(xu, xv, pd); // the frontier's draws (may regenerate: no Y exists then)
+        } else {
+          xu = sh->canon[q], xv = sh->canon[q + 1], pd = sh->canon[q + 2];
+        }
+        const int uS = tp.vPow2 ? sub >> vShift : sub / fbV, vS = sub - uS * fbV;
+        double u, v;
+        stratify(tp, uS, vS, xu, xv, invU, invV, u, v);
+        d3 nd;
+        const bool refl = scatter(*this, s0, d, u, v, pd, nd);
+        Chain c;
+        c.slot = forX ? 0 : (X.slot ^ 1);
+        c.sub = sub, c.start = q, c.pos = q + 3, c.depth = 1, c.levels = 1, c.nlev = 0;
+        c.refl0 = refl, c.live = true, c.done = false, c.pend = false, c.pendLevel = 0, c.pendIdx = 0;
+        c.rays = 0, c.s1 = 0, c.s2 = 0;
+        c.L = mk(0, 0, 0);
+        writeRay(c.slot, s0.pos, nd);
+        if (forX) X = c; else Y = c;
+      }
+      if (!X.live) break; // every sub-sample is committed
+      // ---- one request for the rays in flight ----
+      const bool yFlies = Y.live & !Y.done;
+      markRay(1);
+      searchBegin((1u << X.slot) | (yFlies ? 1u << Y.slot : 0u));
+      chainFlush(X);
+      chainFlush(Y);
+      searchEnd();
+      {
+        const HitKey kX = pickPartials(X.slot);
+        chainAdvance<true>(X, kX);
+      }
+      if (yFlies) {
+        const HitKey kY = pickPartials(Y.slot);
+        chainAdvance<false>(Y, kY);
+      }
+      // ---- commit, in sub-sample order ----
+      while (X.live & X.done) {
+        result = result + (X.refl0 ? s0.emission + X.L : s0.emission + s0.diffuse * X.L);
+        rays += X.rays;
+        pickS2 += pickN * X.s1 + X.s2;
+        pickN += X.rays;
+        hist += 1ull << (6 * X.levels);
+        if (hist & 0x0820820820820820ull) hist = (hist >> 1) & 0x07df7df7df7df7dfull;
+        ++j;
+        if (Y.live & (Y.start == pos)) { // the guess held: Y is the sub-sample at the frontier
+          X = Y;
+          words += 2u * static_cast<unsigned>(Y.pos - Y.start);
+          pos = Y.pos;
+          Y.live = false;
+        } else {
+          X.live = false;
+          Y.live = false;
+        }
+      }
+    }
+    return result * tp.invFirstBounce; // Vec3::operator/(double): multiply by 1.0 / (nU * nV)
   }
 
   // radianceChain() for the REG variant, arranged around what a single wave per SIMD pays for:
@@ -1554,7 +1777,8 @@ __host__ __device__ inline size_t seqLdsBytes(int waves, int maxDepth, bool ldsT
   size_t n = masters * sizeof(SeqShared);
   n += static_cast<size_t>(waves) * (maxDepth > 0 ? maxDepth : 1) * sizeof(Level);
   n = (n + 15) & ~static_cast<size_t>(15); // the answers: 16-byte aligned (ds_read_b128)
-  n += masters * static_cast<size_t>(waves) * sizeof(PartialHit) + kSeqCmdBytes;
+  // (two answer sets per master: the paired form's second command slot; 96 bytes more for the plain one)
+  n += 2 * masters * static_cast<size_t>(waves) * sizeof(PartialHit) + kSeqCmdBytes;
   n = (n + 63) & ~static_cast<size_t>(63);
   if (ldsTables) {
     n += static_cast<size_t>(nsph) * sizeof(SphereRec);
@@ -1564,13 +1788,14 @@ __host__ __device__ inline size_t seqLdsBytes(int waves, int maxDepth, bool ldsT
   return n;
 }
 
-template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false, int MASTERS = 1>
+template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false, int MASTERS = 1, bool PAIR = false, bool PICKS = true>
 __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void traceSequential(
     const TraceParams p, const double *__restrict__ triGeom,
     const TriShade *__restrict__ triShade, const SphereRec *__restrict__ spheres,
     const double *__restrict__ triCompact, const double *__restrict__ matTable,
     uint32_t *__restrict__ mtState, uint32_t *__restrict__ mtPos, double *__restrict__ stage,
-    uint32_t *__restrict__ words, unsigned long long *__restrict__ rayCounters) {
+    uint32_t *__restrict__ words, unsigned long long *__restrict__ rayCounters, uint32_t *__restrict__ picks) {
+  using Ctx = SeqCtx<SLOTS, WAVES, LDS_TABLES, REG, false, MASTERS, PAIR, PICKS>;
   extern __shared__ __attribute__((aligned(64))) unsigned char ldsRaw[];
   (void)triShade;
   const int depthSlots = p.maxDepth > 0 ? p.maxDepth : 1;
@@ -1585,12 +1810,12 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
   // worker waves and an odd maxDepth the stacks end on 8 mod 16)
   const size_t partialsOff = (MASTERS * sizeof(SeqShared) + static_cast<size_t>(WAVES) * depthSlots * sizeof(Level) + 15) &
                              ~static_cast<size_t>(15);
-  size_t off = partialsOff + MASTERS * static_cast<size_t>(WAVES) * sizeof(PartialHit) + kSeqCmdBytes;
+  size_t off = partialsOff + 2 * MASTERS * static_cast<size_t>(WAVES) * sizeof(PartialHit) + kSeqCmdBytes;
   off = (off + 63) & ~static_cast<size_t>(63);
 
   const int pass = blockIdx.x * MASTERS + master;
   const bool hasPass = MASTERS == 1 || static_cast<uint32_t>(pass) < p.npass; // (odd pass count)
-  SeqCtx<SLOTS, WAVES, LDS_TABLES, REG, false, MASTERS> ctx;
+  Ctx ctx;
   ctx.triCompactGlobal = triCompact;
   ctx.matTableGlobal = matTable;
   ctx.p = &p;
@@ -1599,7 +1824,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
   ctx.triGeom = triGeom;
   ctx.spheresGlobal = spheres;
   ctx.sh = &sh;
-  constexpr int kBlock = SeqCtx<SLOTS, WAVES, LDS_TABLES, REG, false, MASTERS>::kBlock;
+  constexpr int kBlock = Ctx::kBlock;
   const bool isWorker = WAVES > 1 && threadIdx.x >= 64 * MASTERS;
   const int lane = threadIdx.x & 63;
   // Worker waves in `tid` order: those on a SIMD of their own pair first, those that share a SIMD
@@ -1628,25 +1853,31 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
         : young ? (nA / 2) * p.seqUnitsA + (workerRank - nA / 2) * p.seqUnitsY
                 : workerRank * p.seqUnitsA);
   }
-  ctx.stack = stacks + master * depthSlots; // only the master waves use a radiance stack
-  // [MASTERS][WAVES] partial results, then the commands (56 B each)
-  ctx.allCmds = reinterpret_cast<SeqCommand *>(partials + MASTERS * WAVES);
-  ctx.partials = isWorker ? partials : partials + master * WAVES;
+  // only the master waves use a radiance stack: one each - two with PAIR, one per chain (the stacks
+  // of the worker waves' indices serve: WAVES >= 2 MASTERS)
+  static_assert(!PAIR || WAVES >= 2 * MASTERS, "a stack per chain");
+  ctx.stack = stacks + master * (PAIR ? 2 : 1) * depthSlots;
+  ctx.stackStride = depthSlots;
+  ctx.hist = 0;
+  ctx.m1 = p.maxDepth;
+  // [MASTERS][2 slots][WAVES] partial results (the plain form uses [MASTERS][WAVES] of them), then the
+  // commands (128 B each) and the worker waves' atomic slots
+  ctx.allCmds = reinterpret_cast<SeqCommand *>(partials + 2 * MASTERS * WAVES);
+  ctx.partials = isWorker ? partials : partials + master * (PAIR ? 2 : 1) * WAVES;
   ctx.cmd = ctx.allCmds + master;
-  ctx.flags = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(ctx.allCmds) + kSeqFlagsOffset);
   ctx.minSlot = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(ctx.allCmds) + kSeqMinSlotOffset) +
-                (isWorker ? static_cast<int>(threadIdx.x >> 6) - MASTERS : 0);
-  ctx.seq = 0;
+                2 * (isWorker ? static_cast<int>(threadIdx.x >> 6) - MASTERS : 0);
   ctx.masterIndex = master;
-  static_assert(MASTERS * sizeof(SeqCommand) <= kSeqFlagsOffset && kSeqFlagsOffset + MASTERS * 8 * sizeof(uint32_t) <= kSeqCmdBytes &&
-                    WAVES <= 8 && kSeqMinSlotOffset + 8 * sizeof(unsigned long long) <= kSeqCmdBytes, "commands, answer numbers and slots fit");
+  ctx.picksOn = PICKS && picks != nullptr;
+  ctx.pickReset();
+  static_assert(2 * sizeof(SeqCommand) <= kSeqMinSlotOffset && WAVES <= 8 &&
+                    kSeqMinSlotOffset + 8 * 2 * sizeof(unsigned long long) <= kSeqCmdBytes, "commands and slots fit");
   ctx.tick = 0;
   ctx.laArmed = false;
   ctx.laPos = -1;
   ctx.laMisses = 0;
   ctx.laTick = 0;
   ctx.pendKind = 0;
-  static_assert(MASTERS * sizeof(SeqCommand) <= kSeqCmdBytes, "commands fit");
   ctx.words = 0;
   ctx.rays = 0;
   ctx.parity = 0;
@@ -1689,10 +1920,8 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
         waveSync();
         if (ctx.pos < kMtDoubles) ctx.rebuildCanonWave();
       }
-      // lock step: "live" / "no rays as of barrier 0"; decoupled: no request yet / done
-      if (lane == 0) ctx.cmd->op = SeqCtx<SLOTS, WAVES, LDS_TABLES, REG, false, MASTERS>::kDecoupled
-                                       ? (hasPass ? 0u : kSeqDone) : (hasPass ? kCmdLive : 0u);
-      if (lane < 8) ctx.flags[master * 8 + lane] = 0u;
+      // "live" / "no rays as of barrier 0"
+      if (lane == 0) ctx.cmd->op = hasPass ? kCmdLive : 0u, ctx.cmd->nrays = 1u;
     }
     __syncthreads();
   }
@@ -1702,8 +1931,8 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
   } else if (!hasPass) {
     ctx.stopWorkers();
   } else {
-  if (MASTERS == 2 && !SeqCtx<SLOTS, WAVES, LDS_TABLES, REG, false, MASTERS>::kDecoupled && master == 1) {
-    ldsBarrier(); // lock step: the second master runs one barrier behind the first
+  if (MASTERS == 2 && master == 1) {
+    ldsBarrier(); // the second master runs one barrier behind the first
     ctx.tick = 1;
   }
   // (raising the master waves' priority over the worker that shares their SIMD - s_setprio 1..3 -
@@ -1724,6 +1953,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
     const int px = static_cast<int>(pix % static_cast<uint32_t>(w));
     const int py = static_cast<int>(pix / static_cast<uint32_t>(w));
     ctx.words = 0;
+    ctx.pickReset();
     const unsigned long long tC0 = ctx.now();
     double r0, r1, r2 = 0, r3 = 0;
     if (lens) {
@@ -1735,12 +1965,15 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
     d3 o, d;
     cameraRay<MASTERS == 2>(p.cam, px, py, r0, r1, r2, r3, o, d);
     ctx.acc(10, tC0, d.x);
-    const d3 L = radiance0(ctx, p, triShade, spheres, o, d);
+    d3 L;
+    if constexpr (PAIR) L = p.maxDepth <= 0 ? mk(0, 0, 0) : ctx.pairPixel(p, o, d);
+    else L = radiance0(ctx, p, triShade, spheres, o, d);
     if (lane == 0) {
       myStage[i * 3 + 0] = L.x;
       myStage[i * 3 + 1] = L.y;
       myStage[i * 3 + 2] = L.z;
       if (words) words[static_cast<size_t>(pass) * p.npix + pix] = ctx.words;
+      if (PICKS && picks) picks[static_cast<size_t>(pass) * p.npix + pix] = ctx.pickS2;
     }
   }
 
@@ -1755,12 +1988,17 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
            ctx.prof[8] / r, ctx.prof[9] / r, ctx.prof[10] / r, ctx.prof[11] / r,
            ((tEnd - tStart) - ctx.prof[0] - ctx.prof[1] - ctx.prof[2] - ctx.prof[3] - ctx.prof[5] -
             ctx.prof[6] - ctx.prof[7] - ctx.prof[8] - ctx.prof[10] - ctx.prof[11]) / r);
-    if (WAVES > 1)
+    if (PAIR)
+      printf("PAIR master, per committed ray: requests=%.3f (with two rays: %.3f) | per request: serial (answers -> next publish)=%.0f "
+             "waitB1=%.0f shadow=%.0f waitB2=%.0f\n",
+             ctx.prof[5] / r, ctx.mprof[5] / r, (double)ctx.mprof[0] / ctx.prof[5], (double)ctx.mprof[1] / ctx.prof[5],
+             (double)ctx.mprof[2] / ctx.prof[5], (double)ctx.mprof[3] / ctx.prof[5]);
+    if (WAVES > 1 && !PAIR)
       printf("MASTER per ray, inside intersect(): publish=%.0f waitB1=%.0f shadow(flush+lookahead)=%.0f waitB2=%.0f pick=%.0f; "
              "outside intersect()=%.0f\n",
              ctx.mprof[0] / r, ctx.mprof[1] / r, ctx.mprof[2] / r, ctx.mprof[3] / r, ctx.mprof[4] / r,
              ((tEnd - tStart) - ctx.prof[5]) / r);
-    if (WAVES > 1) {
+    if (WAVES > 1 && !PAIR) {
       const double px = static_cast<double>(p.pixCount);
       auto avg = [](unsigned long long sum, unsigned long long n) { return n ? static_cast<double>(sum) / n : 0.0; };
       printf("MASTER cycles from an answer to the next published ray (and answers per sample): primary hit %.0f (%.2f) miss %.0f "
@@ -1836,11 +2074,12 @@ __host__ __device__ inline size_t specLdsBytes(uint32_t ntri, uint32_t nmat, uin
   return n < floor ? floor : n;
 }
 
+template <bool PICKS>
 __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
     const TraceParams p, const double *__restrict__ triGeom, const SphereRec *__restrict__ spheres,
     const double *__restrict__ triCompact, const double *__restrict__ matTable,
     uint32_t *__restrict__ mtState, double *__restrict__ specState, double *__restrict__ stage,
-    uint32_t *__restrict__ words, unsigned long long *__restrict__ rayCounters) {
+    uint32_t *__restrict__ words, unsigned long long *__restrict__ rayCounters, uint32_t *__restrict__ picks) {
   extern __shared__ __attribute__((aligned(64))) unsigned char ldsRaw[];
   constexpr int kBlock = 64 * (kSpecWaves + 1);
   char *ring = reinterpret_cast<char *>(ldsRaw);
@@ -1857,7 +2096,7 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
 
-  using Ctx = SeqCtx<1, 1, true, true, true>;
+  using Ctx = SeqCtx<1, 1, true, true, true, 1, false, PICKS>;
   Ctx ctx;
   ctx.triCompactGlobal = triCompact;
   ctx.matTableGlobal = matTable;
@@ -1874,6 +2113,8 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
   ctx.words = 0;
   ctx.rays = 0;
   ctx.parity = 0;
+  ctx.picksOn = PICKS && picks != nullptr;
+  ctx.pickReset();
   ctx.ringBase = ring;
   {
     SphereRec *ls = reinterpret_cast<SphereRec *>(ldsRaw + off);
@@ -2006,6 +2247,8 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
     d3 o, d;
     cameraRay(p.cam, px, py, r0, r1, r2, r3, o, d);
     int sampleDraws = camDraws;
+    ctx.pickReset();
+    uint32_t pickSum = 0, pickBase = 1; // the sample's pick checksum; intersect() calls committed so far
     d3 L = mk(0, 0, 0);
     bool traced = false;
     HitKey k0;
@@ -2013,6 +2256,7 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
     if (p.maxDepth > 0) {
       k0 = ctx.intersect(o, d);
       raysTotal++;
+      if (PICKS) pickSum = ctx.pickS2; // (the primary ray is call 0)
       if (uniformBool(k0.idx == kMiss)) {
         L = ld3(p.env);
       } else {
@@ -2065,6 +2309,7 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
             ctx.setStream(wrap ? fOff ^ kRingStride : fOff, wrap ? np - kMtDoubles : np);
             ctx.words = 0;
             ctx.rays = 0;
+            ctx.pickReset();
             // sub-sample index -> stratum (uS, vS) -> stratified (u, v); ONE decision for the
             // usual power-of-two fan-outs (shift / mask / multiply), the general case apart
             double xu, xv, pd;
@@ -2086,6 +2331,7 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
             mine.L[0] = child.x, mine.L[1] = child.y, mine.L[2] = child.z;
             mine.meta = static_cast<int>(ctx.words >> 1) | (refl ? 0x100 : 0) |
                         (static_cast<int>(ctx.rays) << 16);
+            if (PICKS) mine.pad = static_cast<int>(ctx.pickS1 | (ctx.pickS2 << 16)); // (<= 9 calls of <= 127 primitives)
           }
           SpecResult *slot = results + parity * kSpecWaves;
           if (lane == 0) slot[wave] = mine;
@@ -2125,6 +2371,18 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
           raysTotal += static_cast<unsigned>(meta0 >> 16) + (static_cast<unsigned>(meta1 >> 16) & ok1) +
                        (static_cast<unsigned>(meta2 >> 16) & (ok2a | ok2b)) +
                        (static_cast<unsigned>(meta3 >> 16) & ok3);
+          if (PICKS && picks && wave == 0) { // the committed sub-samples' picks, in sub-sample order
+            auto addPicks = [&](int wv, int meta) {
+              const uint32_t pw = static_cast<uint32_t>(slot[wv].pad);
+              pickSum += pickBase * (pw & 0xffffu) + (pw >> 16);
+              pickBase += static_cast<uint32_t>(meta) >> 16;
+            };
+            addPicks(0, meta0);
+            if (ok1) addPicks(1, meta1);
+            if (ok2a) addPicks(2, meta2);
+            if (ok3) addPicks(3, meta3);
+            if (ok2b) addPicks(2, meta2);
+          }
           if (wave == 0) { // only the wave that stores the sample needs the radiance
             auto add = [&](int wv, int meta) {
               const SpecResult &r = slot[wv];
@@ -2156,6 +2414,7 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
       myStage[i * 3 + 1] = L.y;
       myStage[i * 3 + 2] = L.z;
       if (words) words[static_cast<size_t>(pass) * p.npix + pix] = 2u * static_cast<unsigned>(sampleDraws);
+      if (PICKS && picks) picks[static_cast<size_t>(pass) * p.npix + pix] = pickSum;
     }
   }
 
@@ -2416,10 +2675,6 @@ constexpr int kPixBlock = 256;
 #ifndef PTW_PIX_WAVES
 #define PTW_PIX_WAVES 4
 #endif
-// lock-step kernel: rebuild the first-bounce surface per sub-sample (radiance0Pix) instead of carrying it
-#ifndef PTW_PIX_REBUILD
-#define PTW_PIX_REBUILD 1
-#endif
 
 // Lock-step kernel.  With the first-bounce surface carried through the fan-out it needs 174 VGPRs
 // (two waves per SIMD); measured in that form with the grid-stride loop on Cornell 1024 x 1024 @ 256
@@ -2435,8 +2690,8 @@ constexpr int kPixBlock = 256;
 // before the scatter and its two colours are re-read after the chain - the same loads and the same
 // arithmetic on the same inputs, so the same values.  (The empty asm statements keep the compiler
 // from hoisting the rebuild out of the loop, which would bring the 54 registers back.)
-// Measured against the carried surface (make alt ALT_FLAGS=-DPTW_PIX_REBUILD=0;
-// profiles/r03j_lockstep_rebuild_surface_ab.txt): 10 spilled registers instead of 80, 67 instead of
+// Measured against the carried surface (round 3, profiles/r03j_lockstep_rebuild_surface_ab.txt; that
+// form left the tree in round 5, last revision 916a1dc): 10 spilled registers instead of 80, 67 instead of
 // 548 B of HBM traffic per sample (24 are the algorithmic ones), Cornell 240.5 against 243.0,
 // suzanne 21.0 against 21.6, single-sphere 313 against 304 Msamples/s.
 template <bool BVH>
@@ -2515,11 +2770,7 @@ __device__ __forceinline__ void perPixelSample(const TraceParams &p, const Trace
   }
   d3 o, d;
   cameraRay<true>(p.cam, px, py, r0, r1, r2, r3, o, d);
-#if PTW_PIX_REBUILD
   const d3 L = radiance0Pix(ctx, p, b.triShade, b.spheres, o, d);
-#else
-  const d3 L = radiance0(ctx, p, b.triShade, b.spheres, o, d);
-#endif
   double *out = b.stage + (static_cast<size_t>(pass) * p.pixCount + i) * 3;
   out[0] = L.x, out[1] = L.y, out[2] = L.z;
   if (b.words) b.words[static_cast<size_t>(pass) * p.npix + pix] = ctx.words;
@@ -2958,43 +3209,35 @@ constexpr size_t kLdsTableBudget = 150 * 1024; // bytes of LDS we are willing to
 // Name of the variant the last launch*() call of this thread picked (reported through
 // ptw_kernel_stats so that callers do not have to re-derive the dispatch rules).
 thread_local const char *tlsVariant = "";
-thread_local char tlsVariantBuf[64];
-
-// Share of a master-side worker wave relative to the others, in percent (seqUnitSplit).
-// PTW_SEQ_BALANCE overrides for A/B runs.
-int seqBalanceRatio(int masters) {
-  if (const char *v = std::getenv("PTW_SEQ_BALANCE"))
-    if (std::atoi(v) >= 25 && std::atoi(v) <= 400) return std::atoi(v);
-  return masters == 2 ? PTW_SEQ_BALANCE_MM : PTW_SEQ_BALANCE_ONE;
-}
+thread_local char tlsVariantBuf[80];
 
 // The units of 64 triangles per worker wave: older / younger wave of a worker pair, master-side wave.
-// seqUnitSplit's equal-or-ratio shares by default; PTW_SEQ_UNITS="o,y,m" sets them outright (A/B
-// runs; what does not fit the waves' shares is streamed from memory).
-void seqUnitsFor(uint32_t ntri, int nA, int nB, int ratio, int cap, int &uO, int &uY, int &uM) {
+// Equal shares (seqUnitSplit); two masters, scenes from 31 units on: shares by the wave's place
+// (seqUnitSplitByPlace).  LaunchHints::seqUnits sets them outright (tests, A/B runs; what does not fit
+// the waves' shares is streamed from memory).
+void seqUnitsFor(uint32_t ntri, int nA, int nB, int cap, const LaunchHints &hints, int &uO, int &uY, int &uM) {
   int uA, uB;
-  seqUnitSplit(ntri, nA, nB, ratio, cap, uA, uB);
+  seqUnitSplit(ntri, nA, nB, 100, cap, uA, uB);
   uO = uY = uA, uM = uB;
-  // (two masters, nobody asked for a ratio: shares by the wave's place where that applies)
-  if (nA == 4 && nB == 2 && !std::getenv("PTW_SEQ_BALANCE")) (void)seqUnitSplitByPlace(ntri, PTW_SEQ_YOUNG_PERCENT, cap, uO, uY, uM);
-  if (const char *v = std::getenv("PTW_SEQ_UNITS")) {
-    int o = -1, y = -1, m = -1;
-    if (std::sscanf(v, "%d,%d,%d", &o, &y, &m) == 3 && o >= 0 && y >= 0 && m >= 0 && o <= cap && y <= cap && m <= cap)
-      uO = o, uY = y, uM = m;
-  }
+  if (nA == 4 && nB == 2) (void)seqUnitSplitByPlace(ntri, PTW_SEQ_YOUNG_PERCENT, cap, uO, uY, uM);
+  const int o = hints.seqUnits[0], y = hints.seqUnits[1], m = hints.seqUnits[2];
+  if ((o | y | m) != 0 && o >= 0 && y >= 0 && m >= 0 && o <= cap && y <= cap && m <= cap) uO = o, uY = y, uM = m;
 }
 
-template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false, int MASTERS = 1>
-hipError_t launchSeq(const TraceParams &pIn, const TraceBuffers &b, hipStream_t stream) {
+template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false, int MASTERS = 1, bool PAIR = false>
+hipError_t launchSeq(const TraceParams &pIn, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream) {
   TraceParams p = pIn;
   if (WAVES > 1) {
     int uO, uY, uM;
-    seqUnitsFor(p.ntri, WAVES - MASTERS, MASTERS, seqBalanceRatio(MASTERS), SLOTS, uO, uY, uM);
+    seqUnitsFor(p.ntri, WAVES - MASTERS, MASTERS, SLOTS, hints, uO, uY, uM);
     p.seqUnitsA = uO, p.seqUnitsY = uY, p.seqUnitsB = uM;
   }
-  auto kernel = traceSequential<SLOTS, WAVES, LDS_TABLES, REG, MASTERS>;
-  std::snprintf(tlsVariantBuf, sizeof tlsVariantBuf, "traceSequential<%d,%d,%s,%s%s>", SLOTS, WAVES,
-                LDS_TABLES ? "lds" : "global", REG ? "reg" : "stack", MASTERS == 2 ? ",2 masters" : "");
+  // (one wave per pass: the pick checksum is its own instantiation, see SeqCtx::picksOn)
+  auto kernel = WAVES == 1 && !b.picks ? traceSequential<SLOTS, WAVES, LDS_TABLES, REG, MASTERS, PAIR, WAVES != 1>
+                                       : traceSequential<SLOTS, WAVES, LDS_TABLES, REG, MASTERS, PAIR, true>;
+  std::snprintf(tlsVariantBuf, sizeof tlsVariantBuf, "traceSequential<%d,%d,%s,%s%s%s>", SLOTS, WAVES,
+                LDS_TABLES ? "lds" : "global", REG ? "reg" : "stack", MASTERS == 2 ? ",2 masters" : "",
+                PAIR ? ",paired" : "");
   tlsVariant = tlsVariantBuf;
   const size_t lds = seqLdsBytes(WAVES, p.maxDepth, LDS_TABLES, p.ntri, p.nmat, p.nsph, MASTERS);
   if (lds > 48 * 1024) { // per launch: the attribute belongs to the current device's copy of the kernel
@@ -3006,34 +3249,52 @@ hipError_t launchSeq(const TraceParams &pIn, const TraceBuffers &b, hipStream_t 
   hipLaunchKernelGGL(kernel, dim3((p.npass + MASTERS - 1) / MASTERS),
                      dim3(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)), lds, stream, p, b.triGeom, b.triShade,
                      b.spheres, b.triCompact, b.matTable, b.mtState, b.mtPos, b.stage, b.words,
-                     b.rays);
+                     b.rays, b.picks);
   return hipGetLastError();
 }
 
-template <int SLOTS, int WAVES, int MASTERS = 1>
-hipError_t launchSeqAuto(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
+// ... with the shading tables in LDS when they fit (LaunchHints::seqLdsTables == 0: global memory
+// whatever their size - the tests reach the global-table instantiations with small scenes that way)
+template <int SLOTS, int WAVES, int MASTERS = 1, bool PAIR = false>
+hipError_t launchSeqAuto(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream) {
   const size_t tables = seqLdsBytes(WAVES, p.maxDepth, true, p.ntri, p.nmat, p.nsph, MASTERS);
-  // PTW_SEQ_LDS_TABLES=0: shading tables stay in global memory whatever their size (A/B runs; the
-  // tests use it to reach the global-table instantiations with small scenes)
-  const char *ldsEnv = std::getenv("PTW_SEQ_LDS_TABLES");
-  const bool allowLds = !(ldsEnv && ldsEnv[0] == '0');
-  if (allowLds && tables <= kLdsTableBudget) return launchSeq<SLOTS, WAVES, true, false, MASTERS>(p, b, stream);
-  return launchSeq<SLOTS, WAVES, false, false, MASTERS>(p, b, stream);
+  if (hints.seqLdsTables != 0 && tables <= kLdsTableBudget)
+    return launchSeq<SLOTS, WAVES, true, false, MASTERS, PAIR>(p, b, hints, stream);
+  return launchSeq<SLOTS, WAVES, false, false, MASTERS, PAIR>(p, b, hints, stream);
+}
+
+// The two-master kernels by the largest share of 64-triangle units any worker wave gets; shares are
+// capped at what the register file holds without spilling inside the search loop (11 units = 198
+// registers), the rest of a larger scene is streamed from memory.
+template <bool PAIR>
+hipError_t launchSeqTwoMasters(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream) {
+  int uO, uY, uM;
+  seqUnitsFor(p.ntri, 4, 2, 11, hints, uO, uY, uM);
+  const int need = std::max(uO, std::max(uY, uM));
+  if (need <= 1) return launchSeqAuto<1, 6, 2, PAIR>(p, b, hints, stream);
+  if (need <= 2) return launchSeqAuto<2, 6, 2, PAIR>(p, b, hints, stream);
+  if (need <= 3) return launchSeqAuto<3, 6, 2, PAIR>(p, b, hints, stream);
+  if (need <= 4) return launchSeqAuto<4, 6, 2, PAIR>(p, b, hints, stream);
+  if (need <= 6) return launchSeqAuto<6, 6, 2, PAIR>(p, b, hints, stream);
+  if (need <= 9) return launchSeq<9, 6, false, false, 2, PAIR>(p, b, hints, stream);
+  if (need <= 10) return launchSeq<10, 6, false, false, 2, PAIR>(p, b, hints, stream);
+  return launchSeq<11, 6, false, false, 2, PAIR>(p, b, hints, stream);
 }
 
 
 hipError_t launchSeqSpec(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
   tlsVariant = "traceSequentialSpec";
   const size_t lds = specLdsBytes(p.ntri, p.nmat, p.nsph);
+  auto kernel = b.picks ? traceSequentialSpec<true> : traceSequentialSpec<false>;
   {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(traceSequentialSpec),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds));
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(traceSequentialSpec, dim3(p.npass), dim3(64 * (kSpecWaves + 1)), lds, stream, p,
+  hipLaunchKernelGGL(kernel, dim3(p.npass), dim3(64 * (kSpecWaves + 1)), lds, stream, p,
                      b.triGeom, b.spheres, b.triCompact, b.matTable, b.mtState, b.specState, b.stage,
-                     b.words, b.rays);
+                     b.words, b.rays, b.picks);
   return hipGetLastError();
 }
 
@@ -3089,7 +3350,7 @@ hipError_t launchBuildCandidates(const TraceParams &p, const TraceBuffers &b, in
 #endif
 
 namespace {
-hipError_t dispatchSequential(const TraceParams &p, const TraceBuffers &b, hipStream_t stream);
+hipError_t dispatchSequential(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream);
 int deviceCus();
 // the scenes the register-resident speculative kernels handle (traceSequentialSpec / Gang)
 bool specApplies(const TraceParams &p) {
@@ -3099,35 +3360,22 @@ bool specApplies(const TraceParams &p) {
 }
 
 #if PTW_EXPERIMENTS
-// Workgroups (CUs) per pass for traceSequentialGang: the largest of 8 / 4 that fits the device
-// with every workgroup resident - two CUs per pass measured no gain over one (the meeting costs
-// what the extra four candidates bring).  PTW_SEQ_GANG=0: never; 2, 4, 8: that many when they fit.
-int seqGangGroups(const TraceParams &p) {
-  const char *env = std::getenv("PTW_SEQ_GANG");
-  const char *regEnv = std::getenv("PTW_SEQ_REG");
-  const char *specEnv = std::getenv("PTW_SEQ_SPEC");
-  if ((env && env[0] == '0') || (regEnv && regEnv[0] == '0') || (specEnv && specEnv[0] == '0')) return 0;
+// Workgroups (CUs) per pass for traceSequentialGang (LaunchHints::gangGroups = 2, 4 or 8: that many
+// when every workgroup of the launch can be resident; 0, the default: never - DESIGN.md 3.1d).
+int seqGangGroups(const TraceParams &p, const LaunchHints &hints) {
+  const int g = hints.gangGroups;
+  if (!(g == 2 || g == 4 || g == 8) || hints.seqSmallKernel == 0 || hints.seqSmallKernel == 1) return 0;
   if (!specApplies(p) || p.npass == 0) return 0;
   const uint32_t cus = static_cast<uint32_t>(deviceCus());
-  auto fits = [&](uint32_t g) { return ((p.npass + 7u) / 8u) * 8u * g <= cus; };
-  if (env && (env[0] == '2' || env[0] == '4' || env[0] == '8')) {
-    const uint32_t g = static_cast<uint32_t>(env[0] - '0');
-    return fits(g) ? static_cast<int>(g) : 0;
-  }
-#if PTW_SEQ_GANG_DEFAULT
-  if (fits(8)) return 8;
-  if (fits(4)) return 4;
-#endif
-  return 0;
+  return ((p.npass + 7u) / 8u) * 8u * static_cast<uint32_t>(g) <= cus ? g : 0;
 }
-
 #else
-int seqGangGroups(const TraceParams &) { return 0; } // (the experiments build only)
+int seqGangGroups(const TraceParams &, const LaunchHints &) { return 0; } // (the experiments build only)
 #endif
 
-hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, hipStream_t stream,
-                                 const char **variant) {
-  const hipError_t e = dispatchSequential(p, b, stream);
+hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints,
+                                 hipStream_t stream, const char **variant) {
+  const hipError_t e = dispatchSequential(p, b, hints, stream);
   if (variant) *variant = tlsVariant;
   return e;
 }
@@ -3141,78 +3389,62 @@ int deviceCus() {
   return cus;
 }
 
-hipError_t dispatchSequential(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
+hipError_t dispatchSequential(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream) {
   const uint32_t n = p.ntri;
   // Smallest configuration that keeps every triangle resident in VGPRs.  Up to 128 triangles
   // one wave does everything.  Beyond that 7 worker waves + 1 master wave = 8 waves = 2 per SIMD
   // of one CU (256 registers per lane each): SLOTS triangles per worker lane.
   if (n <= 64) {
     // register-resident shading records + scalar (E, T) stack when the byte-per-level encoding
-    // fits (PTW_SEQ_REG=0 forces the LDS-table variant for A/B runs)
-    const char *regEnv = std::getenv("PTW_SEQ_REG");
-    const bool reg = !(regEnv && regEnv[0] == '0') && p.nsph <= 64 && p.nsph + n <= 127 &&
-                     p.maxDepth <= 9 &&
-                     seqLdsBytes(1, p.maxDepth, true, p.ntri, p.nmat, p.nsph) <= kLdsTableBudget;
-    // ... and, by default, with the fan-out traced speculatively by four waves (PTW_SEQ_SPEC=0: off)
-    // The speculative kernel spends a whole CU on a pass.  That pays while there are at most as many
-    // passes as CUs; with more, one wave per pass on every SIMD is the better use of the chip.
-    const char *specEnv = std::getenv("PTW_SEQ_SPEC");
+    // fits (LaunchHints::seqSmallKernel == 0 forces the LDS-table variant)
+    const bool reg = hints.seqSmallKernel != 0 && specApplies(p);
+    // ... and, by default, with the fan-out traced speculatively by four waves.  The speculative
+    // kernel spends a whole CU on a pass.  That pays while there are at most as many passes as CUs;
+    // with more, one wave per pass on every SIMD is the better use of the chip.
     const int cus = deviceCus();
-    const bool forced = specEnv && specEnv[0] == '2'; // PTW_SEQ_SPEC=2: whatever the pass count
-    if (reg && !(specEnv && specEnv[0] == '0') && b.specState &&
-        (forced || p.npass <= static_cast<uint32_t>(cus))) {
+    const bool forced = hints.seqSmallKernel == 2; // whatever the pass count
+    if (reg && hints.seqSmallKernel != 1 && b.specState && (forced || p.npass <= static_cast<uint32_t>(cus))) {
 #if PTW_EXPERIMENTS
-      // PTW_SEQ_GANG=2|4|8: several CUs per pass (experiments/ptw_gang.h)
+      // several CUs per pass (experiments/ptw_gang.h)
       if (b.gangRecords && b.countHist && b.wideCands)
-        if (const int G = seqGangGroups(p)) return launchSeqGang(p, b, stream, G);
+        if (const int G = seqGangGroups(p, hints)) return b.picks ? hipErrorNotSupported : launchSeqGang(p, b, stream, G);
 #endif
       return launchSeqSpec(p, b, stream);
     }
-    if (reg) return launchSeq<1, 1, true, true>(p, b, stream);
-    return launchSeqAuto<1, 1>(p, b, stream);
+    if (reg) return launchSeq<1, 1, true, true>(p, b, hints, stream);
+    return launchSeqAuto<1, 1>(p, b, hints, stream);
   }
-  if (n <= 128) return launchSeqAuto<2, 1>(p, b, stream);
+  if (n <= 128) return launchSeqAuto<2, 1>(p, b, hints, stream);
   // Beyond 128 triangles a pass occupies a whole CU (8 waves of up to 256 registers), and its
   // workers idle while the master shades.  With more passes than CUs, two passes share a
-  // workgroup instead: two masters over six worker waves, the workers searching one master's ray
+  // workgroup instead: two masters over six worker waves, the workers searching one master's request
   // while the other master shades (measured: suzanne 512 passes 7.2 -> 11.9 Msamples/s, ce 1024
   // passes 1.43 -> 2.02; with no more passes than CUs it would only leave CUs empty).
-  // PTW_SEQ_MM=0 / 1: never / always.
-  const char *mmEnv = std::getenv("PTW_SEQ_MM");
-  const bool mm = mmEnv && (mmEnv[0] == '0' || mmEnv[0] == '1') ? mmEnv[0] == '1'
-                                                                 : p.npass > static_cast<uint32_t>(deviceCus());
-  // The template's SLOTS is the largest share of 64-triangle units any worker wave gets under the
-  // balance ratio (seqUnitSplit); shares are capped at what the register file holds without
-  // spilling inside the search loop (11 units = 198 registers), the rest of a larger scene is
-  // streamed from memory.
+  // LaunchHints::seqTwoMasters 0 / 1: never / always.
+  const bool mm = hints.seqTwoMasters == 0 || hints.seqTwoMasters == 1 ? hints.seqTwoMasters == 1
+                                                                      : p.npass > static_cast<uint32_t>(deviceCus());
   if (mm) {
-    int uO, uY, uM;
-    seqUnitsFor(n, 4, 2, seqBalanceRatio(2), 11, uO, uY, uM);
-    const int need = std::max(uO, std::max(uY, uM));
-    if (need <= 1) return launchSeqAuto<1, 6, 2>(p, b, stream);
-    if (need <= 2) return launchSeqAuto<2, 6, 2>(p, b, stream);
-    if (need <= 3) return launchSeqAuto<3, 6, 2>(p, b, stream);
-    if (need <= 4) return launchSeqAuto<4, 6, 2>(p, b, stream);
-    if (need <= 6) return launchSeqAuto<6, 6, 2>(p, b, stream);
-    if (need <= 9) return launchSeq<9, 6, false, false, 2>(p, b, stream);
-    if (need <= 10) return launchSeq<10, 6, false, false, 2>(p, b, stream);
-    return launchSeq<11, 6, false, false, 2>(p, b, stream);
+    // ... and every request carries two rays (SeqCtx::pairPixel) where the fan-out has sub-samples to
+    // pair and the chains have levels to trace (LaunchHints::seqPairing 0 / 1: never / whenever possible)
+    const bool canPair = p.maxDepth >= 2 && p.maxDepth <= 9 && p.fbU * p.fbV >= 2 && !p.preview;
+    const bool pair = canPair && hints.seqPairing != 0;
+    return pair ? launchSeqTwoMasters<true>(p, b, hints, stream) : launchSeqTwoMasters<false>(p, b, hints, stream);
   }
   int uO, uY, uM;
-  seqUnitsFor(n, 6, 1, seqBalanceRatio(1), 12, uO, uY, uM);
+  seqUnitsFor(n, 6, 1, 12, hints, uO, uY, uM);
   const int need = std::max(uO, std::max(uY, uM));
-  if (need <= 1) return launchSeqAuto<1, 7>(p, b, stream);
-  if (need <= 2) return launchSeqAuto<2, 7>(p, b, stream);
-  if (need <= 3) return launchSeqAuto<3, 7>(p, b, stream);
-  if (need <= 4) return launchSeqAuto<4, 7>(p, b, stream);
-  if (need <= 6) return launchSeq<6, 7, false>(p, b, stream);
-  if (need <= 8) return launchSeq<8, 7, false>(p, b, stream);
-  return launchSeq<12, 7, false>(p, b, stream); // beyond 5376 the tail is streamed from memory
+  if (need <= 1) return launchSeqAuto<1, 7>(p, b, hints, stream);
+  if (need <= 2) return launchSeqAuto<2, 7>(p, b, hints, stream);
+  if (need <= 3) return launchSeqAuto<3, 7>(p, b, hints, stream);
+  if (need <= 4) return launchSeqAuto<4, 7>(p, b, hints, stream);
+  if (need <= 6) return launchSeq<6, 7, false>(p, b, hints, stream);
+  if (need <= 8) return launchSeq<8, 7, false>(p, b, hints, stream);
+  return launchSeq<12, 7, false>(p, b, hints, stream); // beyond 5376 the tail is streamed from memory
 }
 } // namespace
 
-hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipStream_t stream,
-                               const char **variant) {
+hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints,
+                               hipStream_t stream, const char **variant) {
   // Two kernels, each the better one somewhere (one box, one run: profiles/r03a_perpixel_*):
   //   lock-step (tracePerPixel, a lane traces a whole sample, 8 samples per lane through a
   //     grid-stride loop): Cornell 1024x1024 @ 256 spp 224 Msamples/s against 146 - in a closed scene
@@ -3221,9 +3453,8 @@ hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipS
   //   persistent (tracePerPixelPersistent, lanes that finish a path take the next sample): suzanne
   //     44 against 19, bbc-owl 395 against 139 - open scenes, where most paths of a wave end early.
   // p.pixKernel carries the caller's choice (ptw_render_params.pix_kernel, or what ptw_context_calibrate
-  // measured for this scene and frame shape; the persistent kernel when neither).  PTW_PIX_KERNEL
-  // (legacy|persistent) overrides for A/B runs; the accelerated mode has its own kernel.
-  const char *forced = std::getenv("PTW_PIX_KERNEL");
+  // measured for this scene and frame shape; the persistent kernel when neither); the accelerated mode
+  // has its own kernel.
   if (p.accel == PTW_ACCEL_BVH) {
     if (variant) *variant = "tracePerPixelBvh";
     const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
@@ -3238,7 +3469,7 @@ hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipS
     hipLaunchKernelGGL(tracePerPixelBvh, dim3(blocks), dim3(kPixBlock), lds, stream, p, b);
     return hipGetLastError();
   }
-  const bool persistent = forced ? std::string(forced) != "legacy" : p.pixKernel != kPixKernelLockstep;
+  const bool persistent = p.pixKernel != kPixKernelLockstep;
   if (variant) *variant = persistent ? "tracePerPixelPersistent" : "tracePerPixel";
   if (persistent) {
     const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
@@ -3248,9 +3479,8 @@ hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipS
     // persistent grid: W blocks of 256 lanes per CU (W waves per SIMD), fewer for tiny jobs.
     // W = 4: 128 VGPRs with 128 B/lane of scratch outside the triangle loop; 3 waves (153 VGPRs,
     // nothing spilled) measured the same or up to 9 % slower (profiles/r02q_persistent_lean_probe.txt).
-    // PTW_PIX2_W=2|3|4 for A/B runs.
-    const char *wEnv = std::getenv("PTW_PIX2_W");
-    const int W = wEnv && wEnv[0] >= '2' && wEnv[0] <= '4' ? wEnv[0] - '0' : 4;
+    // LaunchHints::pixWavesPerSimd = 2 | 3 | 4 for A/B runs.
+    const int W = hints.pixWavesPerSimd >= 2 && hints.pixWavesPerSimd <= 4 ? hints.pixWavesPerSimd : 4;
     uint64_t blocks = static_cast<uint64_t>(cus) * W;
     const uint64_t needed = (total + kPix2Block - 1) / kPix2Block;
     if (blocks > needed) blocks = needed;
@@ -3276,12 +3506,11 @@ hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, hipS
     return hipGetLastError();
   }
   const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
-  // PTW_PIX_SPL=n: n samples per lane through the kernel's grid-stride loop (default 8; 1 = a block
-  // per 256 samples)
-  const char *splEnv = std::getenv("PTW_PIX_SPL");
+  // LaunchHints::pixSamplesPerLane = n: n samples per lane through the kernel's grid-stride loop (default
+  // 8; 1 = a block per 256 samples)
   // (measured on Cornell 1024x1024 @ 256: 1 -> 194, 4 -> 223, 16 -> 224, 64 -> 219, 256 -> 201 Msamples/s:
   // a block per 256 samples is a million block dispatches per frame)
-  const uint64_t spl = splEnv && std::atoi(splEnv) > 0 ? static_cast<uint64_t>(std::atoi(splEnv)) : 8;
+  const uint64_t spl = hints.pixSamplesPerLane > 0 ? static_cast<uint64_t>(hints.pixSamplesPerLane) : 8;
   const uint32_t blocks = static_cast<uint32_t>((total + kPixBlock * spl - 1) / (kPixBlock * spl));
   const int levels = p.maxDepth > 1 ? p.maxDepth - 1 : 1;
   const size_t lds = static_cast<size_t>(levels) * kPixBlock * sizeof(uint32_t);

@@ -31,6 +31,11 @@ struct Options {
   std::string scene = "cornell";
   std::string scenesDir = "scenes";
   std::string output;
+  // --debug name=value[,name=value...]: the library's dispatch forced from outside (ptw_debug_options:
+  // tests and A/B runs only - the byte-equality tests run every kernel variant through this binary)
+  bool haveDebug = false;
+  ptw_debug_options debug;
+  int shareDevice = 0; // --debug share_device=1|2: every shard of --gpus N on the one device
 };
 
 [[noreturn]] void usageError(const std::string &message) {
@@ -58,8 +63,46 @@ void printHelp() {
                "  --rng <policy>             sequential (reference-exact, default) | perpixel\n"
                "  --accel <mode>             none (the reference's brute force, default) | bvh (perpixel only:\n"
                "                             same image, triangles culled by a bounding-volume hierarchy)\n"
+               "  --pix-kernel <kernel>      perpixel policy: auto (default) | lockstep | persistent\n"
                "  --scenes-dir <dir>         where the .obj/.mtl files live (scenes)\n"
+               "  --debug <name=value,...>   tests / A-B runs only: ptw_debug_options fields (include/ptw.h),\n"
+               "                             share_device=1|2 (--gpus N on one device)\n"
                "  -?, --help\n";
+}
+
+int toInt(const std::string &flag, const char *text);
+
+void parseDebug(Options &o, const std::string &spec) {
+  if (!o.haveDebug) {
+    ptw_debug_defaults(&o.debug);
+    o.haveDebug = true;
+  }
+  size_t at = 0;
+  while (at < spec.size()) {
+    size_t end = spec.find(',', at);
+    if (end == std::string::npos) end = spec.size();
+    const std::string item = spec.substr(at, end - at);
+    at = end + 1;
+    const size_t eq = item.find('=');
+    if (eq == std::string::npos) usageError("--debug wants name=value, got '" + item + "'");
+    const std::string name = item.substr(0, eq), text = item.substr(eq + 1);
+    if (name == "seq_units") { // seq_units=o:y:m
+      if (std::sscanf(text.c_str(), "%d:%d:%d", &o.debug.seq_units[0], &o.debug.seq_units[1], &o.debug.seq_units[2]) != 3)
+        usageError("--debug seq_units wants older:younger:master");
+      continue;
+    }
+    const int v = toInt("--debug " + name, text.c_str());
+    if (name == "seq_two_masters") o.debug.seq_two_masters = v;
+    else if (name == "seq_pairing") o.debug.seq_pairing = v;
+    else if (name == "seq_lds_tables") o.debug.seq_lds_tables = v;
+    else if (name == "seq_small_kernel") o.debug.seq_small_kernel = v;
+    else if (name == "pix_samples_per_lane") o.debug.pix_samples_per_lane = v;
+    else if (name == "pix_waves_per_simd") o.debug.pix_waves_per_simd = v;
+    else if (name == "gang_groups") o.debug.gang_groups = v;
+    else if (name == "trace") o.debug.trace = v;
+    else if (name == "share_device") o.shareDevice = v;
+    else usageError("Unknown --debug option " + name);
+  }
 }
 
 int toInt(const std::string &flag, const char *text) {
@@ -104,7 +147,14 @@ Options parse(int argc, const char *argv[]) {
       if (m == "none") o.params.accel = PTW_ACCEL_NONE;
       else if (m == "bvh") o.params.accel = PTW_ACCEL_BVH;
       else usageError("Unknown accel mode " + m);
-    } else if (a == "-?" || a == "--help") o.help = true;
+    } else if (a == "--pix-kernel") {
+      const std::string m = value(i, a);
+      if (m == "auto") o.params.pix_kernel = PTW_PIX_KERNEL_AUTO;
+      else if (m == "lockstep") o.params.pix_kernel = PTW_PIX_KERNEL_LOCKSTEP;
+      else if (m == "persistent") o.params.pix_kernel = PTW_PIX_KERNEL_PERSISTENT;
+      else usageError("Unknown pix kernel " + m);
+    } else if (a == "--debug") parseDebug(o, value(i, a));
+    else if (a == "-?" || a == "--help") o.help = true;
     else if (!a.empty() && a[0] == '-' && a.size() > 1) usageError("Unrecognised token: " + a);
     else o.output = a;
   }
@@ -221,11 +271,12 @@ int main(int argc, const char *argv[]) {
     // The passes (SEQUENTIAL) or the interleaved image rows (PERPIXEL) are spread over the
     // devices and merged with one RCCL collective on the devices (ptw_render_ex).
     ro.num_devices = o.gpus;
-    ro.share_device = std::getenv("PTW_CLI_SHARE_DEVICE") != nullptr; // tests on a 1-GPU box
+    ro.share_device = o.shareDevice; // (--debug share_device=1: tests on a 1-GPU box)
   } else if (o.saveEvery > 0 && o.params.samples_per_pixel > 1) {
     ro.update = onUpdate;
     ro.update_user = &saver;
   }
+  if (o.haveDebug) ro.debug = &o.debug;
   const int rc = ptw_render_ex(&view, &camera, &o.params, out.rgbSum.data(), out.counts.data(), &ro);
   const auto endTime = std::chrono::system_clock::now();
   ptw_scene_destroy(scene);

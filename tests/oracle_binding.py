@@ -64,6 +64,12 @@ for _lib in (oracle, oracle_fast):
     _lib.oracle_render.argtypes = [C.POINTER(SceneView), C.POINTER(Camera),
                                    C.POINTER(RenderParams), C.c_int32, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.POINTER(C.c_uint64)]
+    _lib.oracle_render_pass_picks.restype = C.c_int
+    _lib.oracle_render_pass_picks.argtypes = [C.POINTER(SceneView), C.POINTER(Camera), C.POINTER(RenderParams),
+                                              C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    _lib.oracle_render_picks.restype = C.c_int
+    _lib.oracle_render_picks.argtypes = [C.POINTER(SceneView), C.POINTER(Camera), C.POINTER(RenderParams), C.c_int32,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
     _lib.oracle_intersect.argtypes = [C.POINTER(SceneView), _PD, _PD]
     _lib.oracle_intersect_spheres.argtypes = [C.POINTER(SceneView), _PD, C.c_double, _PD]
     _lib.oracle_intersect_triangles.argtypes = [C.POINTER(SceneView), _PD, C.c_double, _PD]
@@ -136,6 +142,33 @@ def oracle_render_pass(view, cam, params, pass_index, lib=None):
                                 rad.ctypes.data, words.ctypes.data)
     assert rc == 0 and n >= 0
     return rad, words
+
+
+def oracle_render_pass_picks(view, cam, params, pass_index, lib=None):
+    """One pass with the per-pixel pick checksum: (radiance, words, picks)."""
+    lib = lib or oracle
+    rad = np.zeros((params.height, params.width, 3))
+    words = np.zeros((params.height, params.width), dtype=np.uint32)
+    picks = np.zeros((params.height, params.width), dtype=np.uint32)
+    rc = lib.oracle_render_pass_picks(C.byref(view), C.byref(cam), C.byref(params), pass_index,
+                                      rad.ctypes.data, words.ctypes.data, picks.ctypes.data)
+    assert rc == 0
+    return rad, words, picks
+
+
+def oracle_render_picks(view, cam, params, threads=1, lib=None):
+    """Returns (rgb_sum[h,w,3], counts[h,w], words[spp,h,w], picks[spp,h,w])."""
+    lib = lib or oracle
+    h, w, spp = params.height, params.width, params.samples_per_pixel
+    rgb = np.zeros((h, w, 3))
+    counts = np.zeros((h, w), dtype=np.uint32)
+    words = np.zeros((spp, h, w), dtype=np.uint32)
+    picks = np.zeros((spp, h, w), dtype=np.uint32)
+    rays = C.c_uint64(0)
+    rc = lib.oracle_render_picks(C.byref(view), C.byref(cam), C.byref(params), threads, rgb.ctypes.data,
+                                 counts.ctypes.data, words.ctypes.data, C.byref(rays), picks.ctypes.data)
+    assert rc == 0
+    return rgb, counts, words, picks
 
 
 def oracle_render(view, cam, params, threads=1, want_words=True, lib=None):

@@ -8,9 +8,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def run_cli(pkg, args, cwd, env=None):
+def run_cli(pkg, args, cwd, env=None, debug=None):
+    """`debug`: ptw_debug_options fields for the CLI's --debug flag (dispatch forced for the test);
+    `env`: PTW_STAGE_BUDGET_KB (the one knob the library reads from the environment here) and
+    PTW_USE_EXPERIMENTS (this helper's own: run against the experiments build)."""
     import os
     exe = pkg.LIB_PATH.parent / "pt_three_ways_hip"
+    if debug:
+        args = ["--debug", ",".join(f"{k}={v}" for k, v in debug.items())] + list(args)
     if env and env.get("PTW_USE_EXPERIMENTS"):
         # the experiments build (make experiments) has the same soname in its own directory; the CLI
         # finds the shipped library through RUNPATH=$ORIGIN, which LD_LIBRARY_PATH precedes
@@ -73,17 +78,18 @@ def test_sequential_kernel_variants_write_identical_bytes(pkg, tmp_path, scene, 
     build (several CUs per pass) is held to the same bytes when that build is present."""
     from conftest import ROOT
     args = ["-w", "40", "-h", "28", "--spp", "5", "--seed", "11", "--scene", scene, "--raw", "--save-every", "0"] + extra
-    variants = {"spec": {}, "reg": {"PTW_SEQ_SPEC": "0"}, "plain": {"PTW_SEQ_SPEC": "0", "PTW_SEQ_REG": "0"},
-                "spec_bands": {"PTW_STAGE_BUDGET_KB": "12"},
+    # name -> (environment, --debug fields)
+    variants = {"spec": ({}, {}), "reg": ({}, {"seq_small_kernel": 1}), "plain": ({}, {"seq_small_kernel": 0}),
+                "spec_bands": ({"PTW_STAGE_BUDGET_KB": "12"}, {}),
                 }
     exp = {"PTW_USE_EXPERIMENTS": "1"}
     if (pkg.LIB_PATH.parent / "experiments" / "libptw_hip.so").exists() and not extra:
         variants.update({
-            "gang8": dict(exp, PTW_SEQ_GANG="8"), "gang4_bands": dict(exp, PTW_SEQ_GANG="4", PTW_STAGE_BUDGET_KB="12"),
-            "gang2": dict(exp, PTW_SEQ_GANG="2")})
+            "gang8": (exp, {"gang_groups": 8}), "gang4_bands": (dict(exp, PTW_STAGE_BUDGET_KB="12"), {"gang_groups": 4}),
+            "gang2": (exp, {"gang_groups": 2})})
     blobs = {}
-    for name, env in variants.items():
-        run_cli(pkg, args + [str(tmp_path / f"{name}.raw")], ROOT, env=env)
+    for name, (env, debug) in variants.items():
+        run_cli(pkg, args + [str(tmp_path / f"{name}.raw")], ROOT, env=env, debug=debug)
         blobs[name] = (tmp_path / f"{name}.raw").read_bytes()
     for name in variants:
         assert blobs[name] == blobs["plain"], name
@@ -92,19 +98,21 @@ def test_sequential_kernel_variants_write_identical_bytes(pkg, tmp_path, scene, 
 @pytest.mark.parametrize("scene,spp", [("suzanne", 5), ("ce", 2), ("ce", 3), ("suzanne", 1)])
 def test_two_master_worker_kernel_writes_identical_bytes(pkg, tmp_path, scene, spp):
     """Scenes beyond 128 triangles: the kernel with two passes (two master waves) per workgroup over
-    six shared worker waves against the one-master kernel - same .raw bytes, for even and odd pass
-    counts (an odd count leaves the last workgroup one master without a pass) and when every pass
+    six shared worker waves - in its paired form (two sub-samples in flight per master, the shipped
+    one) and with single-ray requests - against the one-master kernel: same .raw bytes, for even and odd
+    pass counts (an odd count leaves the last workgroup one master without a pass) and when every pass
     parks and resumes its generator between bands."""
     from conftest import ROOT
     args = ["-w", "24", "-h", "18", "--spp", str(spp), "--seed", "4", "--scene", scene, "--raw", "--save-every", "0"]
-    variants = {"one": {"PTW_SEQ_MM": "0"}, "two": {"PTW_SEQ_MM": "1"},
-                "two_bands": {"PTW_SEQ_MM": "1", "PTW_STAGE_BUDGET_KB": "8"}}
-    if (pkg.LIB_PATH.parent / "experiments" / "libptw_hip.so").exists():   # the decoupled protocol (round 4)
-        variants["two_decoupled"] = {"PTW_USE_EXPERIMENTS": "1", "PTW_SEQ_MM": "1"}
-        variants["two_decoupled_bands"] = {"PTW_USE_EXPERIMENTS": "1", "PTW_SEQ_MM": "1", "PTW_STAGE_BUDGET_KB": "8"}
+    bands = {"PTW_STAGE_BUDGET_KB": "8"}
+    variants = {"one": ({}, {"seq_two_masters": 0}),
+                "two_paired": ({}, {"seq_two_masters": 1, "seq_pairing": 1}),
+                "two_paired_bands": (bands, {"seq_two_masters": 1, "seq_pairing": 1}),
+                "two_single": ({}, {"seq_two_masters": 1, "seq_pairing": 0}),
+                "two_single_bands": (bands, {"seq_two_masters": 1, "seq_pairing": 0})}
     blobs = {}
-    for name, env in variants.items():
-        out = run_cli(pkg, args + [str(tmp_path / f"{name}.raw")], ROOT, env=env)
+    for name, (env, debug) in variants.items():
+        run_cli(pkg, args + [str(tmp_path / f"{name}.raw")], ROOT, env=env, debug=debug)
         blobs[name] = (tmp_path / f"{name}.raw").read_bytes()
     for name in variants:
         assert blobs[name] == blobs["one"], name
@@ -117,11 +125,14 @@ def test_perpixel_kernel_variants_write_identical_bytes(pkg, tmp_path, scene):
     from conftest import ROOT
     args = ["-w", "40", "-h", "28", "--spp", "3", "--seed", "9", "--scene", scene, "--rng", "perpixel", "--raw",
             "--save-every", "0"]
-    variants = {"default": {}, "lockstep": {"PTW_PIX_KERNEL": "legacy"}, "w2": {"PTW_PIX2_W": "2"},
-                "w3": {"PTW_PIX2_W": "3"}, "w4": {"PTW_PIX2_W": "4"}}
+    variants = {"default": ([], {}), "lockstep": (["--pix-kernel", "lockstep"], {}),
+                "lockstep_1": (["--pix-kernel", "lockstep"], {"pix_samples_per_lane": 1}),
+                "w2": (["--pix-kernel", "persistent"], {"pix_waves_per_simd": 2}),
+                "w3": (["--pix-kernel", "persistent"], {"pix_waves_per_simd": 3}),
+                "w4": (["--pix-kernel", "persistent"], {"pix_waves_per_simd": 4})}
     blobs = {}
-    for name, env in variants.items():
-        run_cli(pkg, args + [str(tmp_path / f"{name}.raw")], ROOT, env=env)
+    for name, (flags, debug) in variants.items():
+        run_cli(pkg, args + flags + [str(tmp_path / f"{name}.raw")], ROOT, debug=debug)
         blobs[name] = (tmp_path / f"{name}.raw").read_bytes()
     for name in variants:
         assert blobs[name] == blobs["default"], name
@@ -129,14 +140,14 @@ def test_perpixel_kernel_variants_write_identical_bytes(pkg, tmp_path, scene):
 
 def test_gpus_flag_shards_passes_over_host_threads(pkg, tmp_path):
     """--gpus N: one host thread and context per device, pass ranges merged in device order.  On a
-    1-GPU box the shards share the device (PTW_CLI_SHARE_DEVICE); the sum of the two partial frames
+    1-GPU box the shards share the device (--debug share_device=1); the sum of the two partial frames
     equals the single-device frame up to the order of the fp64 additions."""
     from conftest import ROOT
     args = ["-w", "24", "-h", "16", "--spp", "7", "--seed", "3", "--scene", "cornell", "--raw", "--save-every", "0"]
     run_cli(pkg, args + [str(tmp_path / "one.raw")], ROOT)
-    run_cli(pkg, args + ["--gpus", "2", str(tmp_path / "two.raw")], ROOT, env={"PTW_CLI_SHARE_DEVICE": "1"})
+    run_cli(pkg, args + ["--gpus", "2", str(tmp_path / "two.raw")], ROOT, debug={"share_device": 1})
     run_cli(pkg, args + ["--gpus", "3", "--rng", "perpixel", str(tmp_path / "pp3.raw")], ROOT,
-            env={"PTW_CLI_SHARE_DEVICE": "1"})
+            debug={"share_device": 1})
     a_rgb, a_cnt = pkg.raw_load(tmp_path / "one.raw")
     b_rgb, b_cnt = pkg.raw_load(tmp_path / "two.raw")
     assert np.array_equal(a_cnt, b_cnt) and np.all(b_cnt == 7)

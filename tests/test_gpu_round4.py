@@ -126,7 +126,7 @@ cam = scene.build_named("cornell", 16, 12)
 params = pkg.default_params(width=16, height=12, samples_per_pixel=4, seed=1, rng_policy={policy})
 t0 = time.time()
 try:
-    pkg.render(scene, cam, params, num_devices={n}, share_device=2)
+    pkg.render(scene, cam, params, num_devices={n}, share_device=2, debug=pkg.debug_options(silent_shard={silent}))
 except pkg.PtwError as e:
     print("PTW_ERROR", e.status, "after %.1f s" % (time.time() - t0), e)
     sys.exit(0)
@@ -142,8 +142,8 @@ def test_shard_that_never_enters_the_collective_times_out(tmp_path, silent, poli
     enqueued) left everybody waiting.  Now the wait is bounded (PTW_COLLECTIVE_TIMEOUT_S), the
     communicator is aborted, and the render ends with PTW_ERR_HIP."""
     script = tmp_path / "silent.py"
-    script.write_text(SILENT_SCRIPT.format(root=str(ROOT), policy=policy, n=n))
-    env = dict(os.environ, PTW_TEST_SILENT_SHARD=str(silent), PTW_COLLECTIVE_TIMEOUT_S="3")
+    script.write_text(SILENT_SCRIPT.format(root=str(ROOT), policy=policy, n=n, silent=silent))
+    env = dict(os.environ, PTW_COLLECTIVE_TIMEOUT_S="3")
     proc = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=120)
     assert proc.returncode == 0, proc.stdout + proc.stderr
     assert "PTW_ERROR 3" in proc.stdout and "timed out" in proc.stdout, proc.stdout
@@ -225,68 +225,11 @@ def test_rccl_peer_that_exits_is_an_error_not_a_hang(tmp_path):
     assert "WATCHDOG_OK status 3" in text and "NO_ERROR" not in text, text
 
 
-# ---- the decoupled two-master protocol (experiments build only: measured slower) -----
-DECOUPLED_SCRIPT = r"""
-import os, sys
-sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
-import numpy as np
-import torch
-import oracle_binding as ob
-import test_gpu_round3 as r3
-pkg = ob.pkg
-os.environ["PTW_SEQ_MM"] = "1"
-ran = set()
-for ntri, tables, kernel in r3.TWO_MASTER_CASES:
-    for spp, budget_kb in ((3, None), (4, 1)):
-        os.environ.pop("PTW_SEQ_LDS_TABLES", None); os.environ.pop("PTW_STAGE_BUDGET_KB", None)
-        if tables == "global" and ntri < 1400:
-            os.environ["PTW_SEQ_LDS_TABLES"] = "0"
-        if budget_kb:
-            os.environ["PTW_STAGE_BUDGET_KB"] = str(budget_kb)
-        w, h = (12, 10) if budget_kb else (4, 3)
-        scene, cam = r3._soup(pkg, ntri, 2, seed=31 * ntri + spp, w=w, h=h)
-        params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=5)
-        ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(scene.view(), cam, params, threads=4)
-        rgb, cnt, words, variant, launches = r3._render_with_stats(pkg, scene, cam, params)
-        assert variant == kernel, variant
-        assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words), (ntri, tables, spp)
-        assert r3.rel_err(rgb, ref_rgb) < 1e-12
-        ran.add(variant)
-# the BASELINE scenes, natural dispatch (more passes than CUs)
-del os.environ["PTW_SEQ_MM"]; os.environ.pop("PTW_SEQ_LDS_TABLES", None); os.environ.pop("PTW_STAGE_BUDGET_KB", None)
-cus = torch.cuda.get_device_properties(0).multi_processor_count
-for name, edge in (("suzanne", 6), ("ce", 3)):
-    scene = pkg.Scene(); cam = scene.build_named(name, edge, edge)
-    params = pkg.default_params(width=edge, height=edge, samples_per_pixel=cus + 1, seed=2)
-    ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(scene.view(), cam, params, threads=8)
-    rgb, cnt, words, variant, _ = r3._render_with_stats(pkg, scene, cam, params)
-    assert variant.endswith(",2 masters>"), variant
-    assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words), name
-    assert r3.rel_err(rgb, ref_rgb) < 1e-12
-print("DECOUPLED_OK", len(ran))
-"""
-
-
-def test_decoupled_two_master_protocol_matches_oracle(pkg, tmp_path):
-    """masters that do not wait for each other - the workers poll both masters'
-    request numbers in LDS and answer whichever has a ray, no workgroup barrier on the ray path.  Built,
-    bit-identical to the oracle on every two-master instantiation (odd / even passes, parked streams) and
-    on suzanne / ce through the natural dispatch - and measured 3-15 % slower than the lock step (DESIGN.md
-    3.1), so it lives in the experiments build (-DPTW_SEQ_DECOUPLED=1) and runs here in a child process."""
-    lib = pkg.LIB_PATH.parent / "experiments" / "libptw_hip.so"
-    if not lib.exists():
-        pytest.skip("experiments library not built (make -C pt-three-ways_amd experiments)")
-    script = tmp_path / "decoupled.py"
-    script.write_text(DECOUPLED_SCRIPT.format(root=str(ROOT)))
-    proc = subprocess.run([sys.executable, str(script)], env=dict(os.environ, PTW_LIB_PATH=str(lib)),
-                          capture_output=True, text=True, timeout=900)
-    assert proc.returncode == 0 and "DECOUPLED_OK 11" in proc.stdout, proc.stdout[-1500:] + proc.stderr[-3000:]
-
-
 # ---- exact ties in the worker-wave kernels (the round-4 pick and LDS-atomic reduction) -------------
-@pytest.mark.parametrize("masters", ["1", "0"])
+@pytest.mark.parametrize("nbase", [140, 1100])
+@pytest.mark.parametrize("masters,pairing", [(1, 1), (1, 0), (0, 0)])
 @pytest.mark.parametrize("spp", [3, 4])
-def test_worker_wave_kernels_resolve_exact_ties_like_the_reference(pkg, ob, monkeypatch, masters, spp):
+def test_worker_wave_kernels_resolve_exact_ties_like_the_reference(pkg, ob, masters, pairing, spp, nbase):
     """Scene::intersect scans the primitives in insertion order with a strict `<` (Scene.cpp:31,95,118):
     of several primitives hit at EXACTLY the same distance the one inserted first wins - and its
     material decides the path.  A scene of 140 large triangles, each with a copy 20 indices later (the
@@ -294,16 +237,18 @@ def test_worker_wave_kernels_resolve_exact_ties_like_the_reference(pkg, ob, monk
     all with OTHER materials, so that the master's pick over the workers' answers
     ("the minimum distance, then the lowest index among the answers that have it"), the workers' own
     three-or-more-candidates reduction (one LDS atomic on the distance, then the lowest index among the
-    lanes that hold it) and the two-candidates shortcut all meet exact ties on most rays.  Against the
-    oracle: fp64 sums to 1e-12 and every sample's RNG word count, two masters and one."""
-    monkeypatch.setenv("PTW_SEQ_MM", masters)
+    lanes that hold it) and the two-candidates shortcut all meet exact ties on most rays.  1100 base
+    triangles make 3300: the <10,6,global,2 masters> instantiation BASELINE cfg4 runs.  Against the
+    oracle: fp64 sums to 1e-12, every sample's RNG word count and every sample's pick checksum (WHICH of
+    the tied primitives won), two masters (paired and single-ray requests) and one."""
     rng = np.random.default_rng(11)
     scene = pkg.Scene()
     mats = [pkg.material("diffuse", (0.9, 0.2, 0.2)), pkg.material("light", (2.5, 2.0, 1.5)),
             pkg.material("diffuse", (0.2, 0.9, 0.2)), pkg.material("glossy", (0.4, 0.4, 0.9), 1.3, 25.0),
             pkg.material("reflective", (0.8, 0.8, 0.8), 0.6, 6.0)]
-    base = rng.uniform(-2.5, 2.5, (140, 3)) [:, None, :] + rng.uniform(-1.6, 1.6, (140, 3, 3))
-    for b in range(7):                        # blocks of 20 triangles, each followed by its 20 copies (other
+    size = 1.6 if nbase == 140 else 0.7
+    base = rng.uniform(-2.5, 2.5, (nbase, 3)) [:, None, :] + rng.uniform(-size, size, (nbase, 3, 3))
+    for b in range(nbase // 20):              # blocks of 20 triangles, each followed by its 20 copies (other
         for shift in (0, 1):                  # material, index + 20: the same unit of 64, another lane)
             for k in range(20 * b, 20 * b + 20):
                 scene.add_triangle(*base[k], mats[(k + shift) % 5])
@@ -315,12 +260,18 @@ def test_worker_wave_kernels_resolve_exact_ties_like_the_reference(pkg, ob, monk
     w, h = 10, 8
     cam = pkg.set_focus(pkg.look_at((0, 0.3, 6.5), (0, 0, 0), (0, 1, 0), w, h, 50.0), (0, 0, 0), 0.02)
     params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=21)
-    ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(scene.view(), cam, params, threads=4)
+    ref_rgb, ref_cnt, ref_words, ref_picks = ob.oracle_render_picks(scene.view(), cam, params, threads=4)
     import test_gpu_round3 as r3
-    rgb, cnt, words, variant, _ = r3._render_with_stats(pkg, scene, cam, params)
-    assert variant == ("traceSequential<2,6,lds,stack,2 masters>" if masters == "1" else "traceSequential<1,7,lds,stack>"), variant
+    rgb, cnt, words, variant, _, picks = r3._render_with_stats(pkg, scene, cam, params, picks=True, seq_two_masters=masters,
+                                                               seq_pairing=pairing)
+    small = nbase == 140
+    want = {(1, 1): "traceSequential<2,6,lds,stack,2 masters,paired>" if small else "traceSequential<10,6,global,stack,2 masters,paired>",
+            (1, 0): "traceSequential<2,6,lds,stack,2 masters>" if small else "traceSequential<10,6,global,stack,2 masters>",
+            (0, 0): "traceSequential<1,7,lds,stack>" if small else "traceSequential<8,7,global,stack>"}[(masters, pairing)]
+    assert variant == want, variant
     assert np.array_equal(cnt, ref_cnt)
     assert np.array_equal(words, ref_words), "a tie was resolved differently from the reference"
+    assert np.array_equal(picks, ref_picks), "a tie went to another primitive than in the reference"
     assert r3.rel_err(rgb, ref_rgb) < 1e-12
     # the copies really are hit: with the first-inserted triangles removed the image changes
     assert float(np.abs(ref_rgb).sum()) > 0
