@@ -72,7 +72,11 @@
 // (Round 5 removed the A/B paths whose verdict is recorded in DESIGN.md 3.1 - rejection by select,
 // the lane-per-worker pick, radianceChain for the two-master path, the lexicographic pick, the DPP
 // reduction in the worker waves, the balance ratios by side, the decoupled two-master protocol and
-// its polling variants: last revision with all of them is commit 916a1dc.)
+// its polling variants: last revision with all of them is commit 916a1dc.  Also measured in round 5 and
+// not kept: both master waves on ONE SIMD - hardware waves 0 and 4 - with the six workers two to a SIMD
+// on the other three: the masters' work per answer did not change (2.62 k against 2.65 k cycles in the
+// instrumented build: it is not the worker beside them that makes them slow), suzanne 11.66 against
+// 12.04 and ce 2.01 against 2.15 Msamples/s; profiles/r05e_*.)
 
 #if PTW_PROFILE_PHASES
 #define PTW_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
@@ -330,6 +334,17 @@ __device__ __forceinline__ HitKey pickOfAnswers(const PartialHit (&ph)[N]) {
 // per worker wave and ray (pickNearest's LDS atomic).
 constexpr size_t kSeqCmdBytes = 384;
 constexpr size_t kSeqMinSlotOffset = 256; // into the command area; [8 waves][2 rays] x 8 bytes
+// PAIR: per master, the first-bounce scatter directions of the next sub-samples at the stream positions
+// they may start at - 64 entries, one per lane of the master (SeqCtx::fanBuild) - behind the commands
+struct alignas(32) FanEntry {
+  double dir[3];
+  uint32_t ok; // the entry is usable: sub-sample and draws exist, and the draws choose the diffuse lobe
+  uint32_t pad;
+};
+constexpr int kSeqPixRecDoubles = 24; // ... then the pixel's first-bounce surface (SeqCtx::pixRec) ...
+// ... and a copy of the camera: as a kernel argument its 36 dwords sit in scalar registers the master's
+// loop has no room for (they were spilled to vector-register lanes and read back per pixel)
+constexpr size_t kSeqFanBytes = 64 * sizeof(FanEntry) + kSeqPixRecDoubles * sizeof(double) + sizeof(ptw_camera);
 
 // Master -> worker request of the multi-wave sequential kernels: one ray, or - two-master kernels
 // with pairing - two (the second one belongs to the master's speculated chain, see PairMaster).
@@ -418,6 +433,8 @@ struct SeqCtx {
   // stream frontier and the next ray of the sub-sample AFTER it, started at a guessed stream position
   // (pairPixel); the workers test their resident triangles against both.
   static_assert(!PAIR || MASTERS == 2, "paired requests are a form of the two-master kernels");
+  // worker waves that share their SIMD with a master wave (the others sit two to a SIMD among themselves)
+  static constexpr int kSideB = MASTERS;
   Surface laSurf;  // look-ahead inputs: the first-bounce surface, the incoming direction (set once per
   d3 laDir;        // pixel, before the fan-out: inside its loop they are the caller's own values), ...
   double laInvU, laInvV;
@@ -487,6 +504,7 @@ struct SeqCtx {
   // (six scalars, not an array: a run-time index would put it in scratch memory and ruin the timing)
   unsigned long long g00, g01, g10, g11, g20, g21, n00, n01, n10, n11, n20, n21, lastExit;
   int rayKind, lastKind, lastMiss;
+  unsigned long long pairReq, pairReq2, fanBuilds, fanHits, fanMisses;
 #endif
 
   // Triangle held in slot s of this lane.  WAVES == 1: slot-major (slot s of all lanes covers
@@ -502,7 +520,7 @@ struct SeqCtx {
   // triangles resident in the workers' registers (the rest is streamed: localNearest)
   __device__ __forceinline__ uint32_t residentTriangles() const {
     if (WAVES == 1) return static_cast<uint32_t>(kThreads) * SLOTS;
-    constexpr int nB = MASTERS, nA = WAVES - MASTERS;
+    constexpr int nB = kSideB, nA = WAVES - kSideB;
     return static_cast<uint32_t>((nA / 2) * (p->seqUnitsA + p->seqUnitsY) + nB * p->seqUnitsB) * 64u;
   }
 
@@ -551,6 +569,9 @@ struct SeqCtx {
 #endif
     mtRegenerateWave(sh, threadIdx.x & 63);
     laPos = -1; // positions of the old block mean nothing in the new one
+#if PTW_EXPERIMENTS
+    fanOk = 0; // (PAIR: the tabulated scatters belong to the old block)
+#endif
 #if PTW_PROFILE_PHASES
     prof[9] += __builtin_amdgcn_s_memtime() - t0;
 #endif
@@ -771,53 +792,6 @@ struct SeqCtx {
     return key;
   }
 
-  // The same for TWO rays at once (PAIR): every resident triangle is tested against both while its nine
-  // doubles sit in registers.  The rays are wave-uniform and arrive in scalar registers (every
-  // instruction of the test takes at most one of their components as its scalar operand), so a second
-  // ray costs the worker no vector registers beyond its own best-so-far triple.
-  __device__ __forceinline__ void localNearest2(d3 oA, d3 dA, d3 oB, d3 dB, HitKey &keyA, HitKey &keyB) {
-    PTW_T(tA);
-    double bestTA = kInf, bestDetA = 0, bestTB = kInf, bestDetB = 0;
-    uint32_t bestIdxA = kMiss, bestIdxB = kMiss;
-    const uint32_t nsph = p->nsph;
-    if (hasSphere) {
-      testSphere(oA, dA, mk(scx, scy, scz), sr2, static_cast<uint32_t>(tid), bestTA, bestIdxA);
-      testSphere(oB, dB, mk(scx, scy, scz), sr2, static_cast<uint32_t>(tid), bestTB, bestIdxB);
-    }
-    if (nsph > static_cast<uint32_t>(kThreads)) // rare: more spheres than lanes
-      for (uint32_t i = tid + kThreads; i < nsph; i += kThreads) {
-        const SphereRec &r = spheresGlobal[i];
-        testSphere(oA, dA, ld3(r.centre), r.radiusSquared, i, bestTA, bestIdxA);
-        testSphere(oB, dB, ld3(r.centre), r.radiusSquared, i, bestTB, bestIdxB);
-      }
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-      if (s >= myUnits) continue; // (a guard, not a break: see localNearest)
-      const d3 v0 = mk(v0x[s], v0y[s], v0z[s]), e1 = mk(e1x[s], e1y[s], e1z[s]), e2 = mk(e2x[s], e2y[s], e2z[s]);
-      testTriangle(oA, dA, v0, e1, e2, nsph + slotTriangle(s), bestTA, bestIdxA, bestDetA);
-      testTriangle(oB, dB, v0, e1, e2, nsph + slotTriangle(s), bestTB, bestIdxB, bestDetB);
-    }
-    if (p->ntri > residentTriangles()) // rare: more triangles than resident slots
-      for (uint32_t k = residentTriangles() + tid; k < p->ntri; k += kThreads) {
-        const double *g = triGeom + 9 * static_cast<size_t>(k);
-        const d3 v0 = ld3(g), e1 = ld3(g + 3), e2 = ld3(g + 6);
-        testTriangle(oA, dA, v0, e1, e2, nsph + k, bestTA, bestIdxA, bestDetA);
-        testTriangle(oB, dB, v0, e1, e2, nsph + k, bestTB, bestIdxB, bestDetB);
-      }
-#if PTW_PROFILE_PHASES
-    asm volatile("" : "+v"(bestTA), "+v"(bestTB));
-#endif
-    PTW_T(tB);
-    PTW_ACC(0, tA, tB);
-    keyA = pickNearest(bestTA, bestIdxA, bestDetA, minSlot);
-    keyB = pickNearest(bestTB, bestIdxB, bestDetB, minSlot + 1);
-#if PTW_PROFILE_PHASES
-    asm volatile("" : "+v"(keyA.t), "+v"(keyB.t));
-#endif
-    PTW_T(tC);
-    PTW_ACC(1, tB, tC);
-  }
-
   __device__ __forceinline__ void setLookAheadFrame(const Surface &s, d3 dirIn, double invU, double invV) {
     laSurf = s, laDir = dirIn, laInvU = invU, laInvV = invV;
   }
@@ -910,7 +884,6 @@ struct SeqCtx {
       cmd->o[0] = o.x, cmd->o[1] = o.y, cmd->o[2] = o.z;
       cmd->d[0] = d.x, cmd->d[1] = d.y, cmd->d[2] = d.z;
       if (MASTERS == 1) cmd->op = kCmdTrace;
-      if (PAIR) cmd->nrays = 1u; // (mask of live command slots: slot 0 only)
     }
 #if PTW_PROFILE_PHASES
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -920,7 +893,7 @@ struct SeqCtx {
     PTW_T(tMb);
     // the search takes a thousand cycles and more: the stack entry of the level just left ...
     flushPending();
-    if (!PAIR && laArmed) lookAhead(); // ... and the next sub-sample's first-bounce scatter
+    if (laArmed) lookAhead(); // ... and the next sub-sample's first-bounce scatter
 #if PTW_PROFILE_PHASES
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -983,7 +956,16 @@ struct SeqCtx {
     unsigned long long nreq = 0, nreq2 = 0;
     const unsigned long long w0 = __builtin_amdgcn_s_memtime();
 #endif
-    if (MASTERS == 2) {
+    if constexpr (PAIR) {
+#if PTW_EXPERIMENTS
+#if PTW_PROFILE_PHASES
+      workerLoopPair(nreq, nreq2);
+#else
+      unsigned long long unusedA = 0, unusedB = 0;
+      workerLoopPair(unusedA, unusedB);
+#endif
+#endif
+    } else if (MASTERS == 2) {
       // Barrier n is followed by the search of master (n & 1)'s ray, which that master published
       // before it.  A command's `op` holds the barrier index from which its master has no more
       // rays (kCmdLive while it has): a value that reads the same whenever it is looked at, so all
@@ -996,50 +978,14 @@ struct SeqCtx {
           if (other <= n) break;
           continue;
         }
-        if constexpr (PAIR) {
-          // (wave-uniform: the mask of command slots that hold a ray)
-          const uint32_t mask = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(c.nrays)));
-          PartialHit *out = partials + (n & 1) * 2 * WAVES + (tid >> 6);
-          if (mask == 3u) {
-            // both rays into scalar registers: they are operands of every test of the search
-            const d3 oA = mk(readFirstLane(c.o[0]), readFirstLane(c.o[1]), readFirstLane(c.o[2]));
-            const d3 dA = mk(readFirstLane(c.d[0]), readFirstLane(c.d[1]), readFirstLane(c.d[2]));
-            const d3 oB = mk(readFirstLane(c.o2[0]), readFirstLane(c.o2[1]), readFirstLane(c.o2[2]));
-            const d3 dB = mk(readFirstLane(c.d2[0]), readFirstLane(c.d2[1]), readFirstLane(c.d2[2]));
-            HitKey fA, fB;
-            localNearest2(oA, dA, oB, dB, fA, fB);
-            if ((tid & 63) == 0) {
-              PartialHit ph;
-              ph.t = fA.t, ph.pad = 0, ph.idxSign = packAnswer(fA);
-              out[0] = ph;
-              ph.t = fB.t, ph.idxSign = packAnswer(fB);
-              out[WAVES] = ph;
-            }
-#if PTW_PROFILE_PHASES
-            nreq2++;
-#endif
-          } else {
-            const bool second = mask == 2u;
-            const double *ro = second ? c.o2 : c.o, *rd = second ? c.d2 : c.d;
-            const d3 o = mk(ro[0], ro[1], ro[2]);
-            const d3 d = mk(rd[0], rd[1], rd[2]);
-            const HitKey found = localNearest(o, d);
-            if ((tid & 63) == 0) {
-              PartialHit ph;
-              ph.t = found.t, ph.pad = 0, ph.idxSign = packAnswer(found);
-              out[second ? WAVES : 0] = ph;
-            }
-          }
-        } else {
-          const d3 o = mk(c.o[0], c.o[1], c.o[2]);
-          const d3 d = mk(c.d[0], c.d[1], c.d[2]);
-          const HitKey found = localNearest(o, d);
-          if ((tid & 63) == 0) {
-            PartialHit ph;
-            ph.t = found.t, ph.pad = 0;
-            ph.idxSign = packAnswer(found);
-            partials[(n & 1) * WAVES + (tid >> 6)] = ph;
-          }
+        const d3 o = mk(c.o[0], c.o[1], c.o[2]);
+        const d3 d = mk(c.d[0], c.d[1], c.d[2]);
+        const HitKey found = localNearest(o, d);
+        if ((tid & 63) == 0) {
+          PartialHit ph;
+          ph.t = found.t, ph.pad = 0;
+          ph.idxSign = packAnswer(found);
+          partials[(n & 1) * WAVES + (tid >> 6)] = ph;
         }
 #if PTW_PROFILE_PHASES
         nreq++;
@@ -1322,293 +1268,10 @@ struct SeqCtx {
     return L;
   }
 
-  // =========================================================================================
-  // PAIR (two-master kernels, round 5): TWO sub-samples of the first-bounce fan-out in flight per
-  // master.  The stream makes a pass serial but not unpredictable (see traceSequentialSpec): sub-sample
-  // j + 1 starts where j stops, and the number of draws j consumes - three per level it reaches - takes
-  // few values that repeat (suzanne: 3 in four cases of five; ce: always 15).  So next to the chain X of
-  // the sub-sample at the stream frontier the master keeps a chain Y for the sub-sample after it,
-  // started at the position X WOULD leave the stream at if it consumed g = max(m1, levels X has
-  // consumed already) levels, m1 being the most frequent count of this pass so far.  Every request to
-  // the workers carries the next ray of both (command slots 0 and 1; SeqCommand::nrays is the mask of
-  // slots that hold a ray) and comes back with two nearest hits: one barrier pair, one hand-off, one
-  // pick round for two rays - the worker waves, idle half of every tick on suzanne, test their
-  // resident triangles against both while they have them in registers.  When X ends, Y is the
-  // frontier's sub-sample if and only if it started where X stopped (Y.start == pos): then it is
-  // promoted - with whatever it has traced since - and a new Y is started behind it; otherwise it is
-  // dropped and costs nothing but the workers' time.  X's contribution is added when X ends, so the
-  // contributions are added in sub-sample order and the value is the one the serial evaluation defines,
-  // bit for bit; the RNG word count of a sample is the frontier's progress, the ray counter counts
-  // committed sub-samples only.  A chain's in-flight ray lives in its command slot, its (E, T) levels
-  // in its own LDS stack; what stays in registers is a dozen wave-uniform integers per chain.
-  // Y is only started where its worst case (3 maxDepth draws) ends inside the generator block, so a
-  // speculated chain never regenerates - and neither does X while a Y exists (X.start <= Y.start).
-  // =========================================================================================
-  struct Chain {
-    int slot;       // command slot, answers and stack of this chain (0 or 1)
-    int sub;        // sub-sample index
-    int start, pos; // Y: block position of its first / next draw (X draws at the frontier: ctx.pos)
-    int depth;      // depth of the ray in flight (1: the ray that leaves the first-bounce surface)
-    int levels;     // groups of three draws consumed so far (the scatter at the first-bounce surface = 1)
-    int nlev;       // levels on its stack
-    bool refl0;     // lobe taken at the first-bounce surface
-    bool live, done;
-    bool pend;      // the level `pendLevel` (a diffuse triangle bounce) still has to be written to the stack
-    int pendLevel;
-    uint32_t pendIdx;
-    uint32_t rays, s1, s2; // intersect() calls so far; pick checksum partial sums
-    d3 L;           // done: radiance(depth 1) of the sub-sample
-  };
-  int stackStride;         // levels per chain stack: chain c uses stack[c.slot * stackStride + level]
-  unsigned long long hist; // levels consumed by this pass's committed sub-samples (6-bit fields 1..9)
-  int m1;                  // the most frequent of them (refreshed once per pixel)
-
-  __device__ __forceinline__ void writeRay(int slot, d3 o, d3 d) {
-    if ((threadIdx.x & 63) == 0) {
-      double *po = slot ? cmd->o2 : cmd->o, *pd = slot ? cmd->d2 : cmd->d;
-      po[0] = o.x, po[1] = o.y, po[2] = o.z;
-      pd[0] = d.x, pd[1] = d.y, pd[2] = d.z;
-    }
-  }
-  __device__ __forceinline__ void readRay(int slot, d3 &o, d3 &d) const {
-    const double *po = slot ? cmd->o2 : cmd->o, *pd = slot ? cmd->d2 : cmd->d;
-    o = mk(po[0], po[1], po[2]);
-    d = mk(pd[0], pd[1], pd[2]);
-  }
-  __device__ __forceinline__ void chainPush(const Chain &c, int level, d3 e, d3 dif, bool refl) {
-    if ((threadIdx.x & 63) == 0) {
-      Level lv;
-      lv.emission = e;
-      lv.diffuse = dif;
-      lv.reflective = refl;
-      stack[c.slot * stackStride + level] = lv;
-    }
-  }
-  // (called while the workers search: the colours' fetch - triangle record -> material index ->
-  // material, dependent round trips - is off the serial path, as with flushPending())
-  __device__ __forceinline__ void chainFlush(Chain &c) {
-    if (!(c.live && c.pend)) return;
-    const double *r = tab.tri + static_cast<size_t>(c.pendIdx - p->nsph) * kTriCompactDoubles;
-    const double *m = tab.mat + static_cast<size_t>(static_cast<uint32_t>(r[kTriMaterialIndex])) * kMatDoubles;
-    chainPush(c, c.pendLevel, ld3(m), ld3(m + 3), false);
-    c.pend = false;
-  }
-  // The chain has ended with radiance `L` at its innermost level: fold its stack (Scene.cpp:163-175).
-  __device__ __forceinline__ void chainFinish(Chain &c, d3 L) {
-    chainFlush(c);
-    for (int i = c.nlev - 1; i >= 0; --i) {
-      const Level lv = stack[c.slot * stackStride + i];
-      L = uniformBool(lv.reflective) ? lv.emission + L : lv.emission + lv.diffuse * L;
-    }
-    c.L = L;
-    c.done = true;
-  }
-  // The answer `k` to the chain's ray in flight: radianceChain()'s / chainMasterFrom()'s level, once.
-  // IS_X: the frontier chain draws at ctx.pos (and may regenerate); a speculated chain at c.pos.
-  template <bool IS_X>
-  __device__ __forceinline__ void chainAdvance(Chain &c, const HitKey &k) {
-    const uint32_t pv = k.idx == kMiss ? 0u : k.idx + 1u;
-    c.rays += 1u;
-    c.s1 += pv;
-    c.s2 += c.rays * pv;
-    if (uniformBool(k.idx == kMiss)) { // Scene.cpp:131-133
-      chainFinish(c, envColour);
-      return;
-    }
-    if (c.depth + 1 >= p->maxDepth) { // last level: see radianceChain()
-      if (IS_X) skip3(); else c.pos += 3;
-      c.levels += 1;
-      chainFinish(c, emissionAt(k));
-      return;
-    }
-    d3 o, d;
-    readRay(c.slot, o, d);
-    const uint32_t nsph = p->nsph, ntri = p->ntri;
-    const int q = IS_X ? pos : c.pos;
-    const bool inBlock = IS_X ? q + 3 <= kMtDoubles : true;
-    const bool isTri = (k.idx - nsph) < ntri; // unsigned: spheres fail
-    bool handled = false;
-    if (isTri & inBlock) {
-      // the common level (chainMasterFrom): a triangle, the diffuse lobe decided from the record's lobe
-      // threshold as lane-mask logic, all LDS operands waited for once
-      const double *r = tab.tri + static_cast<size_t>(k.idx - nsph) * kTriCompactDoubles;
-      d3 n = ld3(r), bx = ld3(r + 3), by = ld3(r + 6);
-      double thr = r[kTriLobeThreshold];
-      double pd = sh->canon[q + 2];
-      const double *hm = sh->hemi[q];
-      d3 local = mk(hm[0], hm[1], hm[2]);
-      asm volatile("" : "+v"(n.x), "+v"(bx.x), "+v"(by.x), "+v"(thr), "+v"(pd), "+v"(local.x)); // one wait
-      const bool backfacing = k.det < kEpsilon; // Scene.cpp:107
-      const double ndotd = dot(n, d);
-      const double cosThetaI = backfacing ? ndotd : -ndotd;
-      const unsigned long long mNotRefl = __builtin_amdgcn_ballot_w64(!(pd < thr));
-      const unsigned long long mPlain = __builtin_amdgcn_ballot_w64(thr >= 0.0);
-      const unsigned long long mCos = __builtin_amdgcn_ballot_w64(cosThetaI >= 1e-3);
-      const unsigned long long mPos = __builtin_amdgcn_ballot_w64(pd > 0.0);
-      if ((mNotRefl & (mPlain | (mCos & mPos))) != 0) {
-        if (IS_X) pos += 3, words += 6; else c.pos += 3;
-        Basis b;
-        b.x = bx, b.y = by, b.z = n;
-        const double sgn = backfacing ? -1.0 : 1.0;
-        const d3 nd = normalisedNearUnit(transform(b, mk(local.x * sgn, local.y, local.z * sgn)));
-        writeRay(c.slot, o + d * k.t, nd);
-        c.pend = true, c.pendLevel = c.nlev, c.pendIdx = k.idx;
-        c.nlev += 1;
-        handled = true;
-      }
-    }
-    if (!handled) { // sphere, reflective lobe, Fresnel evaluation, draws straddling a regeneration
-      const Surface s = surfaceAt(k, o, d, false);
-      d3 nd;
-      bool refl;
-      if (IS_X) {
-        refl = scatterChain(s, d, nd);
-      } else {
-        refl = scatterChainAt(q, s, d, nd);
-        c.pos += 3;
-      }
-      chainPush(c, c.nlev, s.emission, s.diffuse, refl);
-      c.nlev += 1;
-      writeRay(c.slot, s.pos, nd);
-    }
-    c.depth += 1;
-    c.levels += 1;
-  }
-
-  // One request for the rays in this master's command slots (`mask`: bit c = slot c): publish + B1 ...
-  __device__ __forceinline__ void searchBegin(uint32_t mask) {
-    if ((threadIdx.x & 63) == 0) cmd->nrays = mask;
-#if PTW_PROFILE_PHASES
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    if (lastExit) mprof[0] += t0 - lastExit;
-    mprof[5] += mask == 3u ? 1 : 0;
+#if PTW_EXPERIMENTS
+  // (the PAIR form of the two-master kernels: built and measured slower in round 5 - DESIGN.md 3.1e)
+#include "experiments/ptw_pair.h"
 #endif
-    ldsBarrier(); // B1: the rays are visible to the workers
-#if PTW_PROFILE_PHASES
-    lastExit = __builtin_amdgcn_s_memtime();
-    mprof[1] += lastExit - t0;
-#endif
-  }
-  // ... (the caller's shadow work) ... B2: the answers are there.
-  __device__ __forceinline__ void searchEnd() {
-#if PTW_PROFILE_PHASES
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    mprof[2] += t0 - lastExit;
-#endif
-    ldsBarrier(); // B2
-#if PTW_PROFILE_PHASES
-    lastExit = __builtin_amdgcn_s_memtime();
-    mprof[3] += lastExit - t0;
-    prof[5] += 1;
-#endif
-    tick += 2;
-  }
-
-  // radiance(rng, ray, 0, renderParams) for the PAIR master: radiance0() with the fan-out traced as
-  // described above.  (maxDepth >= 2, at most 9: launchSeq dispatches the plain form otherwise.)
-  __device__ __forceinline__ d3 pairPixel(const TraceParams &tp, d3 o, d3 d) {
-    markRay(0);
-    const HitKey k0 = intersect(o, d);
-    if (uniformBool(k0.idx == kMiss)) return ld3(tp.env);
-    const Surface s0 = surfaceAt(k0, o, d);
-    if (tp.preview) return s0.diffuse; // Scene.cpp:137-138
-    d3 result = mk(0, 0, 0);
-    double invU = tp.invU, invV = tp.invV;
-    asm volatile("" : "+v"(invU), "+v"(invV));
-    const int nSub = tp.fbU * tp.fbV, fbV = tp.fbV;
-    const int vShift = fbV > 0 ? 31 - __builtin_clz(static_cast<unsigned>(fbV)) : 0;
-    const int maxDepth = tp.maxDepth;
-    { // the guess of this pixel: the most frequent number of levels so far (none yet: the depth cap)
-      int best = maxDepth, bestN = 0;
-#pragma unroll
-      for (int f = 1; f <= 9; ++f) {
-        const int n = static_cast<int>(hist >> (6 * f)) & 63;
-        const bool top = n > bestN;
-        best = top ? f : best;
-        bestN = top ? n : bestN;
-      }
-      m1 = best;
-    }
-    Chain X, Y;
-    X.live = false, Y.live = false;
-    X.done = false, Y.done = false;
-    X.pend = false, Y.pend = false;
-    int j = 0; // sub-samples committed
-    for (;;) {
-      // ---- refill: X at the frontier, Y behind it at the guessed position ----
-#pragma nounroll
-      for (int n = 0; n < 2; ++n) {
-        const bool forX = n == 0;
-        int sub, q;
-        if (forX) {
-          if (X.live | (j >= nSub)) continue;
-          sub = j, q = pos;
-        } else {
-          if (!X.live | Y.live | (X.sub + 1 >= nSub)) continue;
-          const int g = m1 > X.levels ? m1 : X.levels;
-          sub = X.sub + 1, q = pos + 3 * (g - X.levels);
-          if (q + 3 * maxDepth > kMtDoubles) continue; // a speculated chain never leaves the block
-        }
-        double xu, xv, pd;
-        if (forX) {
-          draw3(xu, xv, pd); // the frontier's draws (may regenerate: no Y exists then)
-        } else {
-          xu = sh->canon[q], xv = sh->canon[q + 1], pd = sh->canon[q + 2];
-        }
-        const int uS = tp.vPow2 ? sub >> vShift : sub / fbV, vS = sub - uS * fbV;
-        double u, v;
-        stratify(tp, uS, vS, xu, xv, invU, invV, u, v);
-        d3 nd;
-        const bool refl = scatter(*this, s0, d, u, v, pd, nd);
-        Chain c;
-        c.slot = forX ? 0 : (X.slot ^ 1);
-        c.sub = sub, c.start = q, c.pos = q + 3, c.depth = 1, c.levels = 1, c.nlev = 0;
-        c.refl0 = refl, c.live = true, c.done = false, c.pend = false, c.pendLevel = 0, c.pendIdx = 0;
-        c.rays = 0, c.s1 = 0, c.s2 = 0;
-        c.L = mk(0, 0, 0);
-        writeRay(c.slot, s0.pos, nd);
-        if (forX) X = c; else Y = c;
-      }
-      if (!X.live) break; // every sub-sample is committed
-      // ---- one request for the rays in flight ----
-      const bool yFlies = Y.live & !Y.done;
-      markRay(1);
-      searchBegin((1u << X.slot) | (yFlies ? 1u << Y.slot : 0u));
-      chainFlush(X);
-      chainFlush(Y);
-      searchEnd();
-      {
-        const HitKey kX = pickPartials(X.slot);
-        chainAdvance<true>(X, kX);
-      }
-      if (yFlies) {
-        const HitKey kY = pickPartials(Y.slot);
-        chainAdvance<false>(Y, kY);
-      }
-      // ---- commit, in sub-sample order ----
-      while (X.live & X.done) {
-        result = result + (X.refl0 ? s0.emission + X.L : s0.emission + s0.diffuse * X.L);
-        rays += X.rays;
-        pickS2 += pickN * X.s1 + X.s2;
-        pickN += X.rays;
-        hist += 1ull << (6 * X.levels);
-        if (hist & 0x0820820820820820ull) hist = (hist >> 1) & 0x07df7df7df7df7dfull;
-        ++j;
-        if (Y.live & (Y.start == pos)) { // the guess held: Y is the sub-sample at the frontier
-          X = Y;
-          words += 2u * static_cast<unsigned>(Y.pos - Y.start);
-          pos = Y.pos;
-          Y.live = false;
-        } else {
-          X.live = false;
-          Y.live = false;
-        }
-      }
-    }
-    return result * tp.invFirstBounce; // Vec3::operator/(double): multiply by 1.0 / (nU * nV)
-  }
 
   // radianceChain() for the REG variant, arranged around what a single wave per SIMD pays for:
   // every instruction is one issue slot, and a branch - even an untaken one - costs five to ten
@@ -1773,13 +1436,14 @@ struct SeqCtx {
 
 // Bytes of dynamic LDS traceSequential needs (also computed on the host for the launch).
 __host__ __device__ inline size_t seqLdsBytes(int waves, int maxDepth, bool ldsTables, uint32_t ntri,
-                                              uint32_t nmat, uint32_t nsph, int masters = 1) {
+                                              uint32_t nmat, uint32_t nsph, int masters = 1, bool pair = false) {
   size_t n = masters * sizeof(SeqShared);
   n += static_cast<size_t>(waves) * (maxDepth > 0 ? maxDepth : 1) * sizeof(Level);
   n = (n + 15) & ~static_cast<size_t>(15); // the answers: 16-byte aligned (ds_read_b128)
   // (two answer sets per master: the paired form's second command slot; 96 bytes more for the plain one)
   n += 2 * masters * static_cast<size_t>(waves) * sizeof(PartialHit) + kSeqCmdBytes;
   n = (n + 63) & ~static_cast<size_t>(63);
+  if (pair) n += masters * kSeqFanBytes;
   if (ldsTables) {
     n += static_cast<size_t>(nsph) * sizeof(SphereRec);
     n += static_cast<size_t>(ntri) * kTriCompactDoubles * sizeof(double);
@@ -1800,7 +1464,8 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
   (void)triShade;
   const int depthSlots = p.maxDepth > 0 ? p.maxDepth : 1;
   // the master wave(s): wave m < MASTERS runs pass MASTERS * blockIdx.x + m on its own generator
-  const int master = MASTERS == 1 ? 0 : (threadIdx.x >> 6 < MASTERS ? threadIdx.x >> 6 : 0);
+  const int hwWave = static_cast<int>(threadIdx.x >> 6);
+  const int master = MASTERS == 1 ? 0 : (hwWave < MASTERS ? hwWave : 0);
   SeqShared &sh = reinterpret_cast<SeqShared *>(ldsRaw)[master];
   Level *stacks = reinterpret_cast<Level *>(ldsRaw + MASTERS * sizeof(SeqShared));
   PartialHit *partials = reinterpret_cast<PartialHit *>(
@@ -1812,6 +1477,8 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
                              ~static_cast<size_t>(15);
   size_t off = partialsOff + 2 * MASTERS * static_cast<size_t>(WAVES) * sizeof(PartialHit) + kSeqCmdBytes;
   off = (off + 63) & ~static_cast<size_t>(63);
+  unsigned char *fanArea = ldsRaw + off;
+  if (PAIR) off += MASTERS * kSeqFanBytes;
 
   const int pass = blockIdx.x * MASTERS + master;
   const bool hasPass = MASTERS == 1 || static_cast<uint32_t>(pass) < p.npass; // (odd pass count)
@@ -1825,13 +1492,13 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
   ctx.spheresGlobal = spheres;
   ctx.sh = &sh;
   constexpr int kBlock = Ctx::kBlock;
-  const bool isWorker = WAVES > 1 && threadIdx.x >= 64 * MASTERS;
+  const bool isWorker = WAVES > 1 && hwWave >= MASTERS;
   const int lane = threadIdx.x & 63;
   // Worker waves in `tid` order: those on a SIMD of their own pair first, those that share a SIMD
   // with a master wave (waves go to the four SIMDs round robin: wave 4 sits with wave 0, wave 5
   // with wave 1) last - they get the scene's empty slots (SeqCtx::slotTriangle), because the master
   // beside them uses the search time for its look-ahead.
-  int workerRank = static_cast<int>(threadIdx.x >> 6) - MASTERS;
+  int workerRank = hwWave - MASTERS;
   if (WAVES > 1 && isWorker) {
     const int firstShared = 4 - MASTERS, nShared = MASTERS; // worker indices of waves 4 .. 3 + MASTERS
     if (workerRank >= firstShared + nShared) workerRank -= nShared;
@@ -1841,7 +1508,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
   ctx.unitBase = 0, ctx.myUnits = 0;
   if (WAVES > 1 && isWorker) {
     // ranks [0, nA): the workers that share a SIMD with another worker; [nA, WAVES): beside a master
-    constexpr int nA = WAVES - MASTERS;
+    constexpr int nA = WAVES - Ctx::kSideB;
     const bool sideB = workerRank >= nA;
     // ranks [0, nA / 2): the OLDER wave of each worker pair (lower hardware wave index), [nA / 2, nA):
     // the younger one
@@ -1857,16 +1524,16 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
   // of the worker waves' indices serve: WAVES >= 2 MASTERS)
   static_assert(!PAIR || WAVES >= 2 * MASTERS, "a stack per chain");
   ctx.stack = stacks + master * (PAIR ? 2 : 1) * depthSlots;
-  ctx.stackStride = depthSlots;
-  ctx.hist = 0;
-  ctx.m1 = p.maxDepth;
+#if PTW_EXPERIMENTS
+  if constexpr (PAIR) ctx.pairInit(p, fanArea + master * kSeqFanBytes, depthSlots, !isWorker);
+#endif
   // [MASTERS][2 slots][WAVES] partial results (the plain form uses [MASTERS][WAVES] of them), then the
   // commands (128 B each) and the worker waves' atomic slots
   ctx.allCmds = reinterpret_cast<SeqCommand *>(partials + 2 * MASTERS * WAVES);
   ctx.partials = isWorker ? partials : partials + master * (PAIR ? 2 : 1) * WAVES;
   ctx.cmd = ctx.allCmds + master;
   ctx.minSlot = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(ctx.allCmds) + kSeqMinSlotOffset) +
-                2 * (isWorker ? static_cast<int>(threadIdx.x >> 6) - MASTERS : 0);
+                2 * (isWorker ? workerRank : 0);
   ctx.masterIndex = master;
   ctx.picksOn = PICKS && picks != nullptr;
   ctx.pickReset();
@@ -1931,7 +1598,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
   } else if (!hasPass) {
     ctx.stopWorkers();
   } else {
-  if (MASTERS == 2 && master == 1) {
+  if (MASTERS == 2 && !PAIR && master == 1) {
     ldsBarrier(); // the second master runs one barrier behind the first
     ctx.tick = 1;
   }
@@ -1946,8 +1613,13 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
   ctx.g00 = ctx.g01 = ctx.g10 = ctx.g11 = ctx.g20 = ctx.g21 = 0;
   ctx.n00 = ctx.n01 = ctx.n10 = ctx.n11 = ctx.n20 = ctx.n21 = 0;
   ctx.lastExit = 0, ctx.rayKind = 2, ctx.lastKind = 0, ctx.lastMiss = 0;
+  ctx.pairReq = ctx.pairReq2 = ctx.fanBuilds = ctx.fanHits = ctx.fanMisses = 0;
   const unsigned long long tStart = __builtin_amdgcn_s_memtime();
 #endif
+#if PTW_EXPERIMENTS
+  if constexpr (PAIR) ctx.pairRun(p, myStage, words, PICKS ? picks : nullptr, pass); // (the whole pass, and the cadence after it)
+#endif
+  if constexpr (!PAIR) {
   for (uint32_t i = 0; i < p.pixCount; ++i) {
     const uint32_t pix = p.pixBegin + i;
     const int px = static_cast<int>(pix % static_cast<uint32_t>(w));
@@ -1965,9 +1637,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
     d3 o, d;
     cameraRay<MASTERS == 2>(p.cam, px, py, r0, r1, r2, r3, o, d);
     ctx.acc(10, tC0, d.x);
-    d3 L;
-    if constexpr (PAIR) L = p.maxDepth <= 0 ? mk(0, 0, 0) : ctx.pairPixel(p, o, d);
-    else L = radiance0(ctx, p, triShade, spheres, o, d);
+    const d3 L = radiance0(ctx, p, triShade, spheres, o, d);
     if (lane == 0) {
       myStage[i * 3 + 0] = L.x;
       myStage[i * 3 + 1] = L.y;
@@ -1988,11 +1658,6 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
            ctx.prof[8] / r, ctx.prof[9] / r, ctx.prof[10] / r, ctx.prof[11] / r,
            ((tEnd - tStart) - ctx.prof[0] - ctx.prof[1] - ctx.prof[2] - ctx.prof[3] - ctx.prof[5] -
             ctx.prof[6] - ctx.prof[7] - ctx.prof[8] - ctx.prof[10] - ctx.prof[11]) / r);
-    if (PAIR)
-      printf("PAIR master, per committed ray: requests=%.3f (with two rays: %.3f) | per request: serial (answers -> next publish)=%.0f "
-             "waitB1=%.0f shadow=%.0f waitB2=%.0f\n",
-             ctx.prof[5] / r, ctx.mprof[5] / r, (double)ctx.mprof[0] / ctx.prof[5], (double)ctx.mprof[1] / ctx.prof[5],
-             (double)ctx.mprof[2] / ctx.prof[5], (double)ctx.mprof[3] / ctx.prof[5]);
     if (WAVES > 1 && !PAIR)
       printf("MASTER per ray, inside intersect(): publish=%.0f waitB1=%.0f shadow(flush+lookahead)=%.0f waitB2=%.0f pick=%.0f; "
              "outside intersect()=%.0f\n",
@@ -2009,6 +1674,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
   }
 #endif
   ctx.stopWorkers();
+  } // !PAIR
   } // master
   // park the generator for the next band
   if (MASTERS == 1) {
@@ -3239,7 +2905,7 @@ hipError_t launchSeq(const TraceParams &pIn, const TraceBuffers &b, const Launch
                 LDS_TABLES ? "lds" : "global", REG ? "reg" : "stack", MASTERS == 2 ? ",2 masters" : "",
                 PAIR ? ",paired" : "");
   tlsVariant = tlsVariantBuf;
-  const size_t lds = seqLdsBytes(WAVES, p.maxDepth, LDS_TABLES, p.ntri, p.nmat, p.nsph, MASTERS);
+  const size_t lds = seqLdsBytes(WAVES, p.maxDepth, LDS_TABLES, p.ntri, p.nmat, p.nsph, MASTERS, PAIR);
   if (lds > 48 * 1024) { // per launch: the attribute belongs to the current device's copy of the kernel
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -3257,7 +2923,7 @@ hipError_t launchSeq(const TraceParams &pIn, const TraceBuffers &b, const Launch
 // whatever their size - the tests reach the global-table instantiations with small scenes that way)
 template <int SLOTS, int WAVES, int MASTERS = 1, bool PAIR = false>
 hipError_t launchSeqAuto(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream) {
-  const size_t tables = seqLdsBytes(WAVES, p.maxDepth, true, p.ntri, p.nmat, p.nsph, MASTERS);
+  const size_t tables = seqLdsBytes(WAVES, p.maxDepth, true, p.ntri, p.nmat, p.nsph, MASTERS, PAIR);
   if (hints.seqLdsTables != 0 && tables <= kLdsTableBudget)
     return launchSeq<SLOTS, WAVES, true, false, MASTERS, PAIR>(p, b, hints, stream);
   return launchSeq<SLOTS, WAVES, false, false, MASTERS, PAIR>(p, b, hints, stream);
@@ -3424,11 +3090,13 @@ hipError_t dispatchSequential(const TraceParams &p, const TraceBuffers &b, const
   const bool mm = hints.seqTwoMasters == 0 || hints.seqTwoMasters == 1 ? hints.seqTwoMasters == 1
                                                                       : p.npass > static_cast<uint32_t>(deviceCus());
   if (mm) {
-    // ... and every request carries two rays (SeqCtx::pairPixel) where the fan-out has sub-samples to
-    // pair and the chains have levels to trace (LaunchHints::seqPairing 0 / 1: never / whenever possible)
+#if PTW_EXPERIMENTS
+    // LaunchHints::seqPairing == 1: the PAIR form (experiments/ptw_pair.h: two sub-samples in flight per
+    // master, two rays per request) where the fan-out has sub-samples to pair and the chains levels to trace
     const bool canPair = p.maxDepth >= 2 && p.maxDepth <= 9 && p.fbU * p.fbV >= 2 && !p.preview;
-    const bool pair = canPair && hints.seqPairing != 0;
-    return pair ? launchSeqTwoMasters<true>(p, b, hints, stream) : launchSeqTwoMasters<false>(p, b, hints, stream);
+    if (canPair && hints.seqPairing == 1) return launchSeqTwoMasters<true>(p, b, hints, stream);
+#endif
+    return launchSeqTwoMasters<false>(p, b, hints, stream);
   }
   int uO, uY, uM;
   seqUnitsFor(n, 6, 1, 12, hints, uO, uY, uM);

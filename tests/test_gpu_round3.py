@@ -86,20 +86,12 @@ TWO_MASTER_CASES = [
 ]
 
 
-@pytest.mark.parametrize("pairing", [1, 0])
-@pytest.mark.parametrize("ntri,tables,kernel", TWO_MASTER_CASES)
-@pytest.mark.parametrize("spp,budget_kb", [(3, None), (4, 1)])
-def test_two_master_kernels_match_oracle(pkg, ob, monkeypatch, ntri, tables, kernel, spp, budget_kb, pairing):
-    """Every <SLOTS, 6, lds|global, 2 masters> instantiation - paired (two sub-samples in flight per
-    master, the shipped form) and with single-ray requests - against the oracle: odd pass count (the
-    last workgroup's second master has no pass) in one band; even pass count with a staging budget
-    so small that every pass parks and resumes its generator after every few pixels.  Radiance sums,
-    every sample's RNG word count and every sample's pick checksum (which primitive each ray hit)."""
+def two_master_case(pkg, ob, ntri, tables, kernel, spp, budget_kb, pairing=0):
+    """One case of test_two_master_kernels_match_oracle (also run by tests/test_gpu_round5.py against the
+    experiments build, with pairing = 1).  PTW_STAGE_BUDGET_KB must be set by the caller."""
     debug = dict(seq_two_masters=1, seq_pairing=pairing)
     if tables == "global" and ntri < 1400:
         debug["seq_lds_tables"] = 0
-    if budget_kb:
-        monkeypatch.setenv("PTW_STAGE_BUDGET_KB", str(budget_kb))
     w, h = (12, 10) if budget_kb else (4, 3)   # (a band is at least 64 pixels)
     scene, cam = _soup(pkg, ntri, 2, seed=31 * ntri + spp, w=w, h=h)
     params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=5)
@@ -114,10 +106,22 @@ def test_two_master_kernels_match_oracle(pkg, ob, monkeypatch, ntri, tables, ker
     assert rel_err(rgb, ref_rgb) < TOL
 
 
+@pytest.mark.parametrize("ntri,tables,kernel", TWO_MASTER_CASES)
+@pytest.mark.parametrize("spp,budget_kb", [(3, None), (4, 1)])
+def test_two_master_kernels_match_oracle(pkg, ob, monkeypatch, ntri, tables, kernel, spp, budget_kb):
+    """Every <SLOTS, 6, lds|global, 2 masters> instantiation against the oracle: odd pass count (the
+    last workgroup's second master has no pass) in one band; even pass count with a staging budget
+    so small that every pass parks and resumes its generator after every few pixels.  Radiance sums,
+    every sample's RNG word count and every sample's pick checksum (which primitive each ray hit)."""
+    if budget_kb:
+        monkeypatch.setenv("PTW_STAGE_BUDGET_KB", str(budget_kb))
+    two_master_case(pkg, ob, ntri, tables, kernel, spp, budget_kb)
+
+
 @pytest.mark.parametrize("ntri,nsph,kernel", [(300, 0, "<1,6,lds,"), (900, 70, "<3,6,lds,"), (3300, 2, "<10,6,global,")])
 def test_two_master_natural_dispatch_more_passes_than_cus(pkg, ob, ntri, nsph, kernel):
-    """No switch: more passes than the device has CUs selects the two-master kernel, paired, by itself -
-    the situation of BASELINE cfg3 / cfg4 (3300 triangles: the <10,6,global> instantiation cfg4 runs).
+    """No switch: more passes than the device has CUs selects the two-master kernel by itself - the
+    situation of BASELINE cfg3 / cfg4 (3300 triangles: the <10,6,global> instantiation cfg4 runs).
     An odd count, so that the last workgroup runs one master."""
     import torch
     cus = torch.cuda.get_device_properties(0).multi_processor_count
@@ -126,15 +130,14 @@ def test_two_master_natural_dispatch_more_passes_than_cus(pkg, ob, ntri, nsph, k
     params = pkg.default_params(width=4, height=3, samples_per_pixel=spp, seed=9)
     ref_rgb, ref_cnt, ref_words, ref_picks = ob.oracle_render_picks(scene.view(), cam, params, threads=8)
     rgb, cnt, words, variant, _, picks = _render_with_stats(pkg, scene, cam, params, picks=True)
-    assert variant.endswith(",2 masters,paired>") and kernel in variant, variant
+    assert variant.endswith(",2 masters>") and kernel in variant, variant
     assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words) and np.array_equal(picks, ref_picks)
     assert rel_err(rgb, ref_rgb) < TOL
 
 
-@pytest.mark.parametrize("pairing", [1, 0])
 @pytest.mark.parametrize("name,edge,spp,kernel", [("suzanne", 16, 6, "traceSequential<3,6,lds,stack,2 masters"),
                                                   ("ce", 6, 5, "traceSequential<10,6,global,stack,2 masters")])
-def test_two_master_kernels_on_the_baseline_scenes(pkg, ob, name, edge, spp, kernel, pairing):
+def test_two_master_kernels_on_the_baseline_scenes(pkg, ob, name, edge, spp, kernel, pairing=0):
     """suzanne and ce - the scenes of cfg3 / cfg4 - directly against the oracle under the two-master
     kernels they run there.  On ce neither the radiance nor the RNG word counts can depend on which
     primitive a ray hits (every primary ray ends on an emitter of diffuse 0, every ray hits something):
@@ -151,8 +154,7 @@ def test_two_master_kernels_on_the_baseline_scenes(pkg, ob, name, edge, spp, ker
     assert rel_err(rgb, ref_rgb) < TOL
 
 
-@pytest.mark.parametrize("pairing", [1, 0])
-def test_a_dropped_unit_of_triangles_shows_in_the_pick_checksum(pkg, ob, pairing):
+def test_a_dropped_unit_of_triangles_shows_in_the_pick_checksum(pkg, ob, pairing=0):
     """The negative control of the comparisons above ("a worker wave that lost a unit
     of triangles would still pass - and run faster").  On ce ITSELF no output can show that: none of its
     rays ever hits a triangle (tests/test_oracle_picks.py: the frame with and without the mesh is the

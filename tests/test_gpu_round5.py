@@ -1,0 +1,90 @@
+"""GPU: round-5 additions.
+
+* the PAIRED form of the two-master worker-wave kernels (csrc/experiments/ptw_pair.h: two sub-samples of the
+  first-bounce fan-out in flight per master, two rays per request to the workers) - built in round 5,
+  measured slower than round 4's lock step, so it lives in the experiments build and is
+  held to the oracle there, in a child process: every instantiation, the BASELINE scenes, exact ties, the
+  natural dispatch - radiance sums, every sample's RNG word count and pick checksum;
+* BASELINE cfg1's exact shape (cornell 256 x 256 @ 8 spp, seed 1) through the C ABI and through the CLI.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+PAIRED_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+import numpy as np
+import torch
+import oracle_binding as ob
+import test_gpu_round3 as r3
+import test_gpu_round4 as r4
+pkg = ob.pkg
+ran = set()
+for ntri, tables, kernel in r3.TWO_MASTER_CASES:
+    for spp, budget_kb in ((3, None), (4, 1)):
+        os.environ.pop("PTW_STAGE_BUDGET_KB", None)
+        if budget_kb:
+            os.environ["PTW_STAGE_BUDGET_KB"] = str(budget_kb)
+        r3.two_master_case(pkg, ob, ntri, tables, kernel, spp, budget_kb, pairing=1)
+        ran.add(kernel)
+os.environ.pop("PTW_STAGE_BUDGET_KB", None)
+for name, edge, spp, kernel in (("suzanne", 16, 6, "traceSequential<3,6,lds,stack,2 masters"),
+                                ("ce", 6, 5, "traceSequential<10,6,global,stack,2 masters")):
+    r3.test_two_master_kernels_on_the_baseline_scenes(pkg, ob, name, edge, spp, kernel, pairing=1)
+r3.test_a_dropped_unit_of_triangles_shows_in_the_pick_checksum(pkg, ob, pairing=1)
+for nbase in (140, 1100):
+    for spp in (3, 4):
+        r4.test_worker_wave_kernels_resolve_exact_ties_like_the_reference(pkg, ob, 1, spp, nbase, pairing=1)
+# odd fan-outs, other depths, a pinhole camera (two camera draws), an open scene
+for over in (dict(first_bounce_u=3, first_bounce_v=5), dict(max_depth=2), dict(max_depth=9, first_bounce_u=2, first_bounce_v=1),
+             dict(max_depth=3, first_bounce_u=1, first_bounce_v=2)):
+    scene, cam = r3._soup(pkg, 700, 3, seed=17, w=8, h=8)
+    params = pkg.default_params(width=8, height=8, samples_per_pixel=4, seed=3, **over)
+    ref_rgb, ref_cnt, ref_words, ref_picks = ob.oracle_render_picks(scene.view(), cam, params, threads=4)
+    rgb, cnt, words, variant, _, picks = r3._render_with_stats(pkg, scene, cam, params, picks=True, seq_two_masters=1, seq_pairing=1)
+    assert variant.endswith(",2 masters,paired>"), variant
+    assert np.array_equal(words, ref_words) and np.array_equal(picks, ref_picks) and r3.rel_err(rgb, ref_rgb) < 1e-12, over
+print("PAIRED_OK", len(ran))
+"""
+
+
+def test_paired_two_master_kernels_match_oracle_in_the_experiments_build(pkg, tmp_path):
+    lib = pkg.LIB_PATH.parent / "experiments" / "libptw_hip.so"
+    if not lib.exists():
+        pytest.skip("experiments library not built (make -C pt-three-ways_amd experiments)")
+    script = tmp_path / "paired.py"
+    script.write_text(PAIRED_SCRIPT.format(root=str(ROOT)))
+    proc = subprocess.run([sys.executable, str(script)], env=dict(os.environ, PTW_LIB_PATH=str(lib)),
+                          capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0 and "PAIRED_OK 13" in proc.stdout, proc.stdout[-1500:] + proc.stderr[-3000:]
+
+
+def test_baseline_cfg1_shape(pkg, ob, tmp_path):
+    """BASELINE.json configs[0]: CornellBox-Original.obj 256 x 256 @ 8 spp, seed 1 (the reference's
+    CPU-runnable plumbing case, `--scene cornell -w 256 -h 256 --spp 8 --max-cpus 1 --seed 1`): the hip
+    way's frame against the oracle - fp64 sums to 1e-12, every sample's RNG word count exact - and the CLI's
+    .raw against the same sums.  (The hip way keeps all 8 passes; the reference's scheduler drops the last
+    one it launched, src/dod/Scene.cpp:251: INTEGRATION.md says how the two are compared.)"""
+    import test_gpu_cli as cli
+    w = h = 256
+    scene = pkg.Scene()
+    cam = scene.build_named("cornell", w, h)
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=8, seed=1)
+    ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(scene.view(), cam, params, threads=8)
+    import test_gpu_round3 as r3
+    rgb, cnt, words, variant, _ = r3._render_with_stats(pkg, scene, cam, params)
+    assert variant == "traceSequentialSpec"
+    assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words)
+    assert r3.rel_err(rgb, ref_rgb) < 1e-12
+    cli.run_cli(pkg, ["--scene", "cornell", "-w", "256", "-h", "256", "--spp", "8", "--max-cpus", "1", "--seed", "1", "--way", "hip",
+                      "--raw", "--save-every", "0", str(tmp_path / "cfg1.raw")], ROOT)
+    raw_rgb, raw_cnt = pkg.raw_load(tmp_path / "cfg1.raw")
+    assert np.array_equal(raw_cnt, ref_cnt) and np.array_equal(raw_rgb, rgb)
