@@ -222,8 +222,8 @@ typedef struct ptw_debug_options {
   int32_t seq_two_masters;      /* worker-wave kernels (scenes beyond 128 triangles), two passes per
                                    workgroup: -1 the dispatcher's rule (more passes than CUs), 0 never,
                                    1 always                                                           */
-  int32_t seq_pairing;          /* two-master kernels, a second (speculated) sub-sample chain per
-                                   master in every request: -1 the dispatcher's rule, 0 off, 1 on     */
+  int32_t seq_pairing;          /* experiments build only: 1 = the PAIRED form of the two-master kernels
+                                   (two sub-samples in flight per master; measured slower); else off  */
   int32_t seq_lds_tables;       /* shading tables: -1 in LDS when they fit, 0 in global memory        */
   int32_t seq_small_kernel;     /* scenes of at most 64 triangles: -1 the dispatcher's rule, 0 the
                                    plain single-wave kernel (LDS tables, LDS stack), 1 the register

@@ -110,7 +110,6 @@
   int fanOk;               // the table belongs to this pixel's surface and this generator block
   // The pixel's first-bounce surface and incoming direction, in LDS (written once per pixel by lane 0).
   double *pixRec;
-  ptw_camera *camLds;      // the camera, copied to LDS at kernel start
   static constexpr int kPxPos = 0, kPxNormal = 3, kPxBx = 6, kPxBy = 9, kPxRefl = 12, kPxCone = 13, kPxE = 14,
                        kPxD = 17, kPxDir = 20; // (kSeqPixRecDoubles doubles)
   int stackStride;         // levels per chain stack: chain c uses stack[c.slot * stackStride + level]
@@ -124,10 +123,7 @@
     m1 = tp.maxDepth;
     fanTable = reinterpret_cast<FanEntry *>(area);
     pixRec = reinterpret_cast<double *>(fanTable + 64);
-    camLds = reinterpret_cast<ptw_camera *>(pixRec + kSeqPixRecDoubles);
-    const int lane = threadIdx.x & 63;
-    if (isMaster && lane < static_cast<int>(sizeof(ptw_camera) / sizeof(double)))
-      reinterpret_cast<double *>(camLds)[lane] = reinterpret_cast<const double *>(&tp.cam)[lane];
+    (void)isMaster;
     fanOk = 0, fanJ0 = 0, fanQ0 = 0;
   }
 
@@ -332,7 +328,7 @@
                                           int pass) {
     const int lane = threadIdx.x & 63;
     const int width = tp.width;
-    const bool lens = uniformBool(camLds->aperture_radius != 0);
+    const bool lens = uniformBool(cam->aperture_radius != 0);
     const int nSub = tp.fbU * tp.fbV, fbV = tp.fbV;
     const int vShift = fbV > 0 ? 31 - __builtin_clz(static_cast<unsigned>(fbV)) : 0;
     const int maxDepth = tp.maxDepth;
@@ -395,7 +391,7 @@
         r1 = draw();
       }
       d3 o, d;
-      cameraRay<true>(*camLds, px, py, r0, r1, r2, r3, o, d);
+      cameraRay<true>(*cam, px, py, r0, r1, r2, r3, o, d);
       writeRay(c, o, d);
       primSlot = c;
       phase = 1;

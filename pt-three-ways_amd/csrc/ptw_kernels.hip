@@ -344,7 +344,11 @@ struct alignas(32) FanEntry {
 constexpr int kSeqPixRecDoubles = 24; // ... then the pixel's first-bounce surface (SeqCtx::pixRec) ...
 // ... and a copy of the camera: as a kernel argument its 36 dwords sit in scalar registers the master's
 // loop has no room for (they were spilled to vector-register lanes and read back per pixel)
-constexpr size_t kSeqFanBytes = 64 * sizeof(FanEntry) + kSeqPixRecDoubles * sizeof(double) + sizeof(ptw_camera);
+constexpr size_t kSeqFanBytes = 64 * sizeof(FanEntry) + kSeqPixRecDoubles * sizeof(double);
+// Worker-wave kernels: a copy of the camera in LDS.  As part of the kernel argument its 36 dwords sit in
+// scalar registers the master's loop has no room for: they were spilled to vector-register lanes and read
+// back for every pixel; from LDS the camera ray reads them with one wait.
+constexpr size_t kSeqCamBytes = (sizeof(ptw_camera) + 63) & ~static_cast<size_t>(63);
 
 // Master -> worker request of the multi-wave sequential kernels: one ray, or - two-master kernels
 // with pairing - two (the second one belongs to the master's speculated chain, see PairMaster).
@@ -354,9 +358,10 @@ struct alignas(16) SeqCommand {
   double o[3], d[3];   // ray A
   double o2[3], d2[3]; // ray B (nrays == 2)
   uint32_t op;         // one master: kCmdTrace / kCmdExit; two masters: see workerLoop
-  uint32_t nrays;      // two masters: rays in this request (1 or 2)
+  uint32_t nrays;      // (PAIR, experiments build: mask of the slots that hold a ray)
   uint32_t pad[6];     // 128 bytes
 };
+static_assert(sizeof(SeqCommand) == 128, "SeqCommand layout");
 
 // std::mt19937 regeneration (the "twist") + tempering + generate_canonical for all 312
 // doubles, by the 64 lanes of one wave.  Chunks of 64 consecutive k are processed in order;
@@ -466,6 +471,7 @@ struct SeqCtx {
   bool hasSphere;
 
   const TraceParams *p;
+  const ptw_camera *cam; // worker-wave kernels: the LDS copy of p->cam
   const double *triGeom;
   const SphereRec *spheresGlobal;
   const double *triCompactGlobal; // REG: source of the per-lane shading records
@@ -987,6 +993,10 @@ struct SeqCtx {
           ph.idxSign = packAnswer(found);
           partials[(n & 1) * WAVES + (tid >> 6)] = ph;
         }
+        // (Round 5 also had the worker wave that answers LAST - an LDS counter per master - pick the
+        // nearest of the six answers, so that the master reads one: the 0.4 k cycles moved from the
+        // master's tick to the search's tail, and suzanne ran 10.0 against 11.7, ce 1.90 against 2.11
+        // Msamples/s, profiles/r05h_*: the tick is the maximum of both, not the master's alone.)
 #if PTW_PROFILE_PHASES
         nreq++;
 #endif
@@ -1443,6 +1453,7 @@ __host__ __device__ inline size_t seqLdsBytes(int waves, int maxDepth, bool ldsT
   // (two answer sets per master: the paired form's second command slot; 96 bytes more for the plain one)
   n += 2 * masters * static_cast<size_t>(waves) * sizeof(PartialHit) + kSeqCmdBytes;
   n = (n + 63) & ~static_cast<size_t>(63);
+  if (waves > 1) n += kSeqCamBytes; // the camera (worker-wave kernels: see traceSequential)
   if (pair) n += masters * kSeqFanBytes;
   if (ldsTables) {
     n += static_cast<size_t>(nsph) * sizeof(SphereRec);
@@ -1477,8 +1488,11 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
                              ~static_cast<size_t>(15);
   size_t off = partialsOff + 2 * MASTERS * static_cast<size_t>(WAVES) * sizeof(PartialHit) + kSeqCmdBytes;
   off = (off + 63) & ~static_cast<size_t>(63);
+  ptw_camera *camLds = reinterpret_cast<ptw_camera *>(ldsRaw + off);
+  if (WAVES > 1) off += kSeqCamBytes;
   unsigned char *fanArea = ldsRaw + off;
   if (PAIR) off += MASTERS * kSeqFanBytes;
+  (void)fanArea;
 
   const int pass = blockIdx.x * MASTERS + master;
   const bool hasPass = MASTERS == 1 || static_cast<uint32_t>(pass) < p.npass; // (odd pass count)
@@ -1570,6 +1584,12 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
   } else {
     ctx.hasSphere = false;
   }
+  ctx.cam = &p.cam;
+  if (WAVES > 1) {
+    if (threadIdx.x < sizeof(ptw_camera) / sizeof(double))
+      reinterpret_cast<double *>(camLds)[threadIdx.x] = reinterpret_cast<const double *>(&p.cam)[threadIdx.x];
+    ctx.cam = camLds; // (visible after the barrier below)
+  }
 
   // resume this pass's generator
   uint32_t *myState = mtState + static_cast<size_t>(hasPass ? pass : 0) * kMtWords;
@@ -1605,7 +1625,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
   // (raising the master waves' priority over the worker that shares their SIMD - s_setprio 1..3 -
   // measured no difference on suzanne and ce: profiles/r03e_master_priority_and_balance.txt)
   const int w = p.width;
-  const bool lens = p.cam.aperture_radius != 0;
+  const bool lens = WAVES > 1 ? uniformBool(ctx.cam->aperture_radius != 0) : p.cam.aperture_radius != 0;
   double *myStage = stage + static_cast<size_t>(pass) * p.pixCount * 3;
 #if PTW_PROFILE_PHASES
   for (int i = 0; i < 12; ++i) ctx.prof[i] = 0;
@@ -1635,7 +1655,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
       r1 = ctx.draw();
     }
     d3 o, d;
-    cameraRay<MASTERS == 2>(p.cam, px, py, r0, r1, r2, r3, o, d);
+    cameraRay<MASTERS == 2>(*ctx.cam, px, py, r0, r1, r2, r3, o, d);
     ctx.acc(10, tC0, d.x);
     const d3 L = radiance0(ctx, p, triShade, spheres, o, d);
     if (lane == 0) {
@@ -1730,7 +1750,7 @@ __host__ __device__ inline size_t specLdsBytes(uint32_t ntri, uint32_t nmat, uin
   size_t n = 2 * kRingStride;                          // the ring
   n += kMtWords * sizeof(uint32_t);                    // raw generator state
   n += 2 * kSpecWaves * sizeof(SpecResult);            // results, double-buffered
-  n += 64;                                             // generator commands
+  n += 64 + kSeqCamBytes;                              // generator commands, the camera
   n = (n + 63) & ~static_cast<size_t>(63);
   n += static_cast<size_t>(nsph) * sizeof(SphereRec);
   n += static_cast<size_t>(ntri) * kTriCompactDoubles * sizeof(double);
@@ -1756,7 +1776,13 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
   constexpr size_t kGenCmdOffset = 2 * kRingStride + kMtWords * sizeof(uint32_t) + 2 * kSpecWaves * sizeof(SpecResult);
   uint32_t *genCmd = reinterpret_cast<uint32_t *>(ldsRaw + kGenCmdOffset);
   size_t off = 2 * kRingStride + kMtWords * sizeof(uint32_t) + 2 * kSpecWaves * sizeof(SpecResult) + 64;
+  // (the camera in LDS: as part of the kernel argument its 36 dwords were spilled to vector-register lanes
+  // and read back for every pixel - see kSeqCamBytes)
+  ptw_camera *camLds = reinterpret_cast<ptw_camera *>(ldsRaw + off);
+  off += kSeqCamBytes;
   off = (off + 63) & ~static_cast<size_t>(63);
+  if (threadIdx.x < sizeof(ptw_camera) / sizeof(double))
+    reinterpret_cast<double *>(camLds)[threadIdx.x] = reinterpret_cast<const double *>(&p.cam)[threadIdx.x];
 
   const int pass = blockIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
@@ -1870,7 +1896,7 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
   };
 
   const int w = p.width;
-  const bool lens = p.cam.aperture_radius != 0;
+  const bool lens = uniformBool(camLds->aperture_radius != 0);
   const int nSub = p.fbU * p.fbV;
   const int vShift = p.fbV > 0 ? 31 - __builtin_clz(static_cast<unsigned>(p.fbV)) : 0;
   // Per-round constants in vector registers: as kernel arguments they sit in a 16-register
@@ -1911,7 +1937,7 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
     }
     const int camDraws = lens ? 4 : 2;
     d3 o, d;
-    cameraRay(p.cam, px, py, r0, r1, r2, r3, o, d);
+    cameraRay(*camLds, px, py, r0, r1, r2, r3, o, d);
     int sampleDraws = camDraws;
     ctx.pickReset();
     uint32_t pickSum = 0, pickBase = 1; // the sample's pick checksum; intersect() calls committed so far
