@@ -559,6 +559,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     device = device_of(local_rank, rank)
+    if use_dist and world > 1:
+        # so that the line can say which wire the framebuffer collective crossed (`rccl_transport`): RCCL
+        # names its transports in its INFO log - to a per-process file, not the terminal (read when the
+        # first RCCL communicator of the process is made, i.e. below)
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,P2P,NET,SHM")
+        os.environ.setdefault("NCCL_DEBUG_FILE", f"/tmp/ptw_bench_rccl_{os.getpid()}_%h_%p.log")
     # launched by torch.distributed.run (even with one rank): one process per GPU
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -694,6 +701,14 @@ def main():
             "resolve_kernel_ms_total": stats.resolve_ms,
             "notes": "profiles/bench_notes.json",
         }
+        if shard.comm is not None and world > 1:
+            try:   # rank 0's view: its GPU's links, the transport that follows, RCCL's own channel lines
+                d = shard.comm.describe()
+                links = sorted({ln["type"] for ln in d.get("links", [])})
+                result["rccl_transport"] = {"expected": d.get("expected"), "rccl_log": d.get("rccl_log"),
+                                            "link_types_from_gpu0": links, "p2p_disabled": d.get("p2p_disabled")}
+            except Exception as e:  # noqa: BLE001
+                result["rccl_transport"] = {"error": repr(e)[:200]}
 
     # -- the other RNG policy, same workload, same run: at N > 1 it is the tile-sharded form
     #    north_star words (image rows interleaved over the GPUs + one RCCL gather) ---------------

@@ -350,6 +350,8 @@ int ptw_context_rng_doubles(ptw_context *ctx, int32_t rng_policy, uint32_t seed,
 #define PTW_COMM_ID_BYTES 128
 typedef struct ptw_comm ptw_comm;
 int ptw_comm_unique_id(uint8_t id_out[PTW_COMM_ID_BYTES]);
+/* (Both set-up calls give up with PTW_ERR_HIP after PTW_COLLECTIVE_TIMEOUT_S - default 300 s - when a
+ * rank of the world never arrives; ncclCommInitRank would otherwise wait for it for ever.) */
 int ptw_comm_create(const uint8_t id[PTW_COMM_ID_BYTES], int32_t world_size, int32_t rank,
                     int32_t device, ptw_comm **out);
 int ptw_comm_create_all(int32_t num_devices, const int32_t *devices, ptw_comm **out_comms);
@@ -370,6 +372,16 @@ void ptw_comm_destroy(ptw_comm *comm);
  * returns PTW_ERR_HIP.  The collectives are asynchronous and a peer that disappears after the
  * enqueue would otherwise leave hipStreamSynchronize waiting forever. */
 int ptw_comm_wait(ptw_comm *comm, void *hip_stream, int32_t timeout_ms);
+/* Which wire the communicator's collectives use, as a JSON object in `out` (NUL-terminated; at most
+ * `capacity` bytes - 4096 are plenty): {"kind": "rccl" | "loopback", "world", "rank", "device",
+ * "links": [{"device", "type": "xgmi" | "pcie" | ..., "hops", "peer_access"}...] (HIP's report for this
+ * rank's GPU against every other visible one), "p2p_disabled", "shm_disabled" (NCCL_P2P_DISABLE /
+ * NCCL_SHM_DISABLE), "expected": the transport RCCL should therefore pick ("P2P/xGMI", "SHM",
+ * "NET/Socket" ...), "rccl_log": the transports RCCL itself names in its channel lines ("P2P/IPC",
+ * "NET/Socket/0" ...) when its log goes to a file (NCCL_DEBUG=INFO with NCCL_DEBUG_FILE; null otherwise;
+ * channels are connected at the first collective, so ask after one)}.  So that the first run on an
+ * 8-GPU node can say whether the framebuffer gather crossed xGMI. */
+int ptw_comm_describe(ptw_comm *comm, char *out, size_t capacity);
 /* `output += pass` for whole framebuffers (ArrayOutput::operator+=, ArrayOutput.cpp:48-56):
  * the fp64 sums (npix * 3) and the u32 counts (npix) of every rank are summed into rank `root`'s
  * buffers (ncclReduce; the other ranks' buffers are left as they are).  In place. */

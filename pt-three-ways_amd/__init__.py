@@ -179,6 +179,7 @@ _sig("ptw_comm_create_loopback", C.c_int, C.c_int32, C.c_int32, C.POINTER(C.c_vo
 _sig("ptw_comm_abort", C.c_int, C.c_void_p)
 _sig("ptw_comm_destroy", None, C.c_void_p)
 _sig("ptw_comm_wait", C.c_int, C.c_void_p, C.c_void_p, C.c_int32)
+_sig("ptw_comm_describe", C.c_int, C.c_void_p, C.c_char_p, C.c_size_t)
 _sig("ptw_comm_reduce_framebuffer", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
      C.c_int32, C.c_void_p)
 _sig("ptw_comm_gather_rows", C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
@@ -409,6 +410,14 @@ class Comm:
         if self._h:
             lib.ptw_comm_destroy(self._h)
             self._h = C.c_void_p()
+
+    def describe(self) -> dict:
+        """Which wire this communicator uses (ptw_comm_describe): HIP's link report for this rank's GPU, the
+        transport RCCL should therefore pick, and what RCCL's own log names when it goes to a file."""
+        import json
+        buf = C.create_string_buffer(4096)
+        _check(lib.ptw_comm_describe(self._h, buf, len(buf)))
+        return json.loads(buf.value.decode())
 
     def wait(self, stream: int = 0, timeout_ms: int = 0):
         """Completion of everything enqueued on `stream` under the watchdog (ptw_comm_wait): an

@@ -27,15 +27,19 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <future>
 #include <memory>
 #include <mutex>
+#include <set>
+#include <sstream>
 #include <string>
 #include <thread>
 #include <vector>
@@ -123,9 +127,12 @@ std::chrono::milliseconds collectiveTimeout(int32_t timeoutMs = 0) {
 // timeout, the caller aborts the communicator from here - ncclCommAbort is the one RCCL call that
 // may be made while another thread is inside the library, and it is what unblocks that thread.
 // (The handle is an atomic: whoever exchanges it for null - this function's timeout path, or
-// ptw_comm_abort on another thread - is the one caller of ncclCommAbort.)
+// ptw_comm_abort on another thread - is the one caller of ncclCommAbort; `guard` keeps that call apart
+// from ptw_comm_wait's ncclCommGetAsyncError on the same handle, which ncclCommAbort frees.)
+// One helper thread per group of collective calls: a frame has ONE such group (the reduce or the gather
+// at its end, seconds to minutes of rendering apart), so the thread's few tens of microseconds do not show.
 template <typename Body>
-void runAbortable(std::atomic<ncclComm_t> &comm, int device, const char *what, Body &&body) {
+void runAbortable(std::atomic<ncclComm_t> &comm, std::mutex &guard, int device, const char *what, Body &&body) {
   std::promise<void> done;
   std::future<void> fut = done.get_future();
   std::thread helper([&] {
@@ -138,13 +145,66 @@ void runAbortable(std::atomic<ncclComm_t> &comm, int device, const char *what, B
     }
   });
   if (fut.wait_for(collectiveTimeout()) != std::future_status::ready) {
-    if (const ncclComm_t c = comm.exchange(nullptr)) (void)rccl().commAbort(c);
+    {
+      std::lock_guard<std::mutex> lock(guard);
+      if (const ncclComm_t c = comm.exchange(nullptr)) (void)rccl().commAbort(c);
+    }
     helper.join();
     throw DeviceError(PTW_ERR_HIP, std::string(what) + " did not return within the timeout (a peer that never "
                                        "arrived?): communicator aborted");
   }
   helper.join();
   fut.get();
+}
+
+// Communicator set-up under the same deadline.  ncclCommInitRank blocks until EVERY rank of the world
+// has called it: a rank that never arrives (a process that died before its set-up) used to leave the
+// others in it for good, where no later watchdog reaches.  There is no communicator to abort yet, so
+// the call runs on a helper thread that is ABANDONED when the deadline passes (it stays blocked in the
+// bootstrap until the process ends; should it ever return, it destroys what it created): the caller gets
+// PTW_ERR_HIP instead of a hang.
+struct InitState {
+  std::mutex m;
+  std::condition_variable cv;
+  bool done = false, abandoned = false;
+  std::exception_ptr error;
+  std::vector<ncclComm_t> comms;
+};
+template <typename Body>
+std::vector<ncclComm_t> runInitAbortable(const char *what, Body body) {
+  auto state = std::make_shared<InitState>();
+  std::thread helper([state, body] {
+    std::vector<ncclComm_t> made;
+    std::exception_ptr err;
+    try {
+      made = body();
+    } catch (...) {
+      err = std::current_exception();
+    }
+    std::unique_lock<std::mutex> lock(state->m);
+    if (state->abandoned) { // nobody is waiting any more: nobody will own these
+      lock.unlock();
+      for (ncclComm_t c : made)
+        if (c) (void)rccl().commAbort(c);
+      return;
+    }
+    state->comms = std::move(made);
+    state->error = err;
+    state->done = true;
+    state->cv.notify_all();
+  });
+  std::unique_lock<std::mutex> lock(state->m);
+  if (!state->cv.wait_for(lock, collectiveTimeout(), [&] { return state->done; })) {
+    state->abandoned = true;
+    lock.unlock();
+    helper.detach();
+    throw DeviceError(PTW_ERR_HIP, std::string(what) + " did not return within the timeout (PTW_COLLECTIVE_TIMEOUT_S; a rank "
+                                       "that never called it?): communicator set-up given up");
+  }
+  lock.unlock();
+  helper.join();
+  if (state->error) std::rethrow_exception(state->error);
+  return state->comms;
 }
 
 // ---- loopback transport ---------------------------------------------------------------------
@@ -210,6 +270,7 @@ using namespace ptw;
 
 struct ptw_comm {
   std::atomic<ncclComm_t> comm{nullptr}; // RCCL transport (null once aborted: see runAbortable)
+  std::mutex guard;                       // ncclCommAbort (frees the handle) against ncclCommGetAsyncError on it
   std::shared_ptr<LoopbackHub> hub;   // loopback transport (comm == nullptr)
   // loopback: one `ready` event per (destination, channel) and one `consumed` event per (source,
   // channel), created on first use and re-recorded for every message - a long-lived communicator
@@ -323,9 +384,14 @@ int ptw_comm_create(const uint8_t id[PTW_COMM_ID_BYTES], int32_t world_size, int
   c->device = device;
   ncclUniqueId uid;
   std::memcpy(uid.internal, id, PTW_COMM_ID_BYTES);
-  ncclComm_t raw = nullptr;
-  checkNccl(rccl().commInitRank(&raw, world_size, uid, rank), "ncclCommInitRank");
-  c->comm = raw;
+  const Rccl &api = rccl();
+  const std::vector<ncclComm_t> made = runInitAbortable("ncclCommInitRank", [&api, world_size, uid, rank, device] {
+    checkHip(hipSetDevice(device), "hipSetDevice");
+    ncclComm_t raw = nullptr;
+    checkNccl(api.commInitRank(&raw, world_size, uid, rank), "ncclCommInitRank");
+    return std::vector<ncclComm_t>{raw};
+  });
+  c->comm = made.at(0);
   *out = c.release();
   return PTW_OK;
   PTW_GUARD_END
@@ -336,8 +402,12 @@ int ptw_comm_create_all(int32_t num_devices, const int32_t *devices, ptw_comm **
   PTW_GUARD_BEGIN
   std::vector<int> devs(static_cast<size_t>(num_devices));
   for (int i = 0; i < num_devices; ++i) devs[i] = devices ? devices[i] : i;
-  std::vector<ncclComm_t> raw(static_cast<size_t>(num_devices), nullptr);
-  checkNccl(rccl().commInitAll(raw.data(), num_devices, devs.data()), "ncclCommInitAll");
+  const Rccl &api = rccl();
+  const std::vector<ncclComm_t> raw = runInitAbortable("ncclCommInitAll", [&api, num_devices, devs] {
+    std::vector<ncclComm_t> made(static_cast<size_t>(num_devices), nullptr);
+    checkNccl(api.commInitAll(made.data(), num_devices, devs.data()), "ncclCommInitAll");
+    return made;
+  });
   for (int i = 0; i < num_devices; ++i) {
     auto *c = new ptw_comm;
     c->comm = raw[i];
@@ -372,9 +442,12 @@ int ptw_comm_abort(ptw_comm *comm) {
   PTW_GUARD_BEGIN
   if (comm->hub) {
     comm->hub->abort();
-  } else if (const ncclComm_t c = comm->comm.exchange(nullptr)) {
-    // ncclCommAbort frees the communicator: kernels of it that wait for a peer on the device end
-    checkNccl(rccl().commAbort(c), "ncclCommAbort");
+  } else {
+    std::lock_guard<std::mutex> lock(comm->guard); // (not while ptw_comm_wait looks at the handle)
+    if (const ncclComm_t c = comm->comm.exchange(nullptr)) {
+      // ncclCommAbort frees the communicator: kernels of it that wait for a peer on the device end
+      checkNccl(rccl().commAbort(c), "ncclCommAbort");
+    }
   }
   return PTW_OK;
   PTW_GUARD_END
@@ -404,20 +477,143 @@ int ptw_comm_wait(ptw_comm *comm, void *hip_stream, int32_t timeout_ms) {
         aborted = comm->hub->aborted;
       }
       if (aborted) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
-    } else if (const ncclComm_t nc = comm->comm.load()) {
-      ncclResult_t async = ncclSuccess;
-      const ncclResult_t r = rccl().commGetAsyncError(nc, &async);
+    } else {
+      // (the handle is looked at under the guard: a ptw_comm_abort on another thread - the documented way
+      // to release a rank that waits here - frees it)
+      ncclResult_t r = ncclSuccess, async = ncclSuccess;
+      bool gone = false;
+      {
+        std::lock_guard<std::mutex> lock(comm->guard);
+        if (const ncclComm_t nc = comm->comm.load())
+          r = rccl().commGetAsyncError(nc, &async);
+        else
+          gone = true;
+      }
+      if (gone) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
       if (r != ncclSuccess) giveUp(std::string("ncclCommGetAsyncError: ") + rccl().getErrorString(r));
       if (async != ncclSuccess && async != ncclInProgress)
         giveUp(std::string("asynchronous RCCL error: ") + rccl().getErrorString(async));
-    } else {
-      throw DeviceError(PTW_ERR_HIP, "communicator aborted");
     }
     if (std::chrono::steady_clock::now() >= deadline)
       giveUp("the collective did not complete within the timeout (a peer that never arrived?)");
     // a framebuffer collective takes well under a millisecond to a few: poll closely first
     std::this_thread::sleep_for(std::chrono::microseconds(spin < 200 ? 50 : 1000));
   }
+  PTW_GUARD_END
+}
+
+} // extern "C"
+
+// ---- which wire? ---------------------------------------------------------------------------
+namespace {
+const char *linkTypeName(uint32_t t) {
+  switch (t) { // hsa_amd_link_info_type_t
+  case 0: return "hypertransport";
+  case 1: return "qpi";
+  case 2: return "pcie";
+  case 3: return "infiniband";
+  case 4: return "xgmi";
+  default: return "unknown";
+  }
+}
+bool envIsOne(const char *name) {
+  const char *v = std::getenv(name);
+  return v && v[0] == '1';
+}
+// NCCL_DEBUG_FILE with RCCL's %h (host name) and %p (process id) filled in; empty: not set
+std::string rcclDebugFile() {
+  const char *v = std::getenv("NCCL_DEBUG_FILE");
+  if (!v || !*v) return std::string();
+  std::string out;
+  for (const char *c = v; *c; ++c) {
+    if (c[0] == '%' && c[1] == 'h') {
+      char host[256] = "";
+      (void)gethostname(host, sizeof host - 1);
+      out += host;
+      ++c;
+    } else if (c[0] == '%' && c[1] == 'p') {
+      out += std::to_string(static_cast<long>(getpid()));
+      ++c;
+    } else {
+      out += *c;
+    }
+  }
+  return out;
+}
+} // namespace
+
+extern "C" {
+
+int ptw_comm_describe(ptw_comm *comm, char *out, size_t capacity) {
+  if (!comm || !out || capacity == 0) return invalid("null pointer");
+  PTW_GUARD_BEGIN
+  std::ostringstream js;
+  js << "{\"kind\": \"" << (comm->hub ? "loopback" : "rccl") << "\", \"world\": " << comm->world << ", \"rank\": " << comm->rank
+     << ", \"device\": " << comm->device;
+  if (comm->hub) {
+    js << ", \"expected\": \"in-process device-to-device copies (one GPU)\", \"links\": [], \"rccl_log\": null}";
+  } else {
+    // the wires of this rank's GPU: link type and hops to every other visible device (HIP's own report)
+    int count = 0;
+    (void)hipGetDeviceCount(&count);
+    bool allXgmi = count > 1, anyPeer = false;
+    js << ", \"links\": [";
+    bool first = true;
+    for (int d = 0; d < count; ++d) {
+      if (d == comm->device) continue;
+      uint32_t type = 0xffffffffu, hops = 0;
+      const hipError_t e = hipExtGetLinkTypeAndHopCount(comm->device, d, &type, &hops);
+      int canAccess = 0;
+      (void)hipDeviceCanAccessPeer(&canAccess, comm->device, d);
+      if (!first) js << ", ";
+      first = false;
+      js << "{\"device\": " << d << ", \"type\": \"" << (e == hipSuccess ? linkTypeName(type) : "unknown") << "\", \"hops\": " << hops
+         << ", \"peer_access\": " << (canAccess ? "true" : "false") << "}";
+      anyPeer = true;
+      if (!(e == hipSuccess && type == 4 && canAccess)) allXgmi = false;
+    }
+    js << "]";
+    const bool p2pOff = envIsOne("NCCL_P2P_DISABLE"), shmOff = envIsOne("NCCL_SHM_DISABLE");
+    js << ", \"p2p_disabled\": " << (p2pOff ? "true" : "false") << ", \"shm_disabled\": " << (shmOff ? "true" : "false");
+    const char *expected = p2pOff ? (shmOff ? "NET/Socket" : "SHM")
+                                  : (!anyPeer ? "one visible GPU: the peers are other hosts to RCCL (NET)"
+                                              : (allXgmi ? "P2P/xGMI" : "P2P (not every peer over xGMI: see links)"));
+    js << ", \"expected\": \"" << expected << "\"";
+    // ... and what RCCL says it chose, when its log goes to a file (NCCL_DEBUG=INFO, NCCL_DEBUG_FILE): the
+    // transports named after "via" in its channel lines
+    const std::string file = rcclDebugFile();
+    std::set<std::string> seen;
+    bool haveLog = false;
+    if (!file.empty()) {
+      std::ifstream in(file);
+      std::string line;
+      while (std::getline(in, line)) {
+        haveLog = true;
+        const size_t at = line.find(" via ");
+        if (at == std::string::npos) continue;
+        std::string word = line.substr(at + 5);
+        const size_t end = word.find_first_of(" \t\r\n");
+        if (end != std::string::npos) word.resize(end);
+        if (!word.empty() && word.size() < 48 && word.find('"') == std::string::npos) seen.insert(word);
+      }
+    }
+    if (!haveLog) {
+      js << ", \"rccl_log\": null}";
+    } else {
+      js << ", \"rccl_log\": [";
+      bool f2 = true;
+      for (const std::string &w : seen) {
+        if (!f2) js << ", ";
+        f2 = false;
+        js << "\"" << w << "\"";
+      }
+      js << "]}";
+    }
+  }
+  const std::string text = js.str();
+  if (text.size() + 1 > capacity) throw std::invalid_argument("ptw_comm_describe: buffer too small");
+  std::memcpy(out, text.c_str(), text.size() + 1);
+  return PTW_OK;
   PTW_GUARD_END
 }
 
@@ -454,7 +650,7 @@ int ptw_comm_reduce_framebuffer(ptw_comm *comm, void *d_rgb_sum, void *d_counts,
   const ncclComm_t nc = comm->comm.load();
   if (!nc) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
   const Rccl &api = rccl();
-  runAbortable(comm->comm, comm->device, "ncclReduce of the framebuffer", [&] {
+  runAbortable(comm->comm, comm->guard, comm->device, "ncclReduce of the framebuffer", [&] {
     // one group: both reductions are launched together
     checkNccl(api.groupStart(), "ncclGroupStart");
     checkNccl(api.reduce(d_rgb_sum, d_rgb_sum, npix * 3, ncclDouble, ncclSum, root, nc, stream),
@@ -507,7 +703,7 @@ int ptw_comm_gather_rows(ptw_comm *comm, void *d_rgb_sum, void *d_counts, int32_
       }
       return PTW_OK;
     }
-    runAbortable(comm->comm, comm->device, "ncclSend of the rows", [&] {
+    runAbortable(comm->comm, comm->guard, comm->device, "ncclSend of the rows", [&] {
       checkNccl(api->groupStart(), "ncclGroupStart");
       if (rows) {
         checkNccl(api->send(packRgb, rows * w * 3, ncclDouble, root, nc, stream), "ncclSend(rgb)");
@@ -532,7 +728,7 @@ int ptw_comm_gather_rows(ptw_comm *comm, void *d_rgb_sum, void *d_counts, int32_
       });
     }
   } else {
-    runAbortable(comm->comm, comm->device, "ncclRecv of the rows", [&] {
+    runAbortable(comm->comm, comm->guard, comm->device, "ncclRecv of the rows", [&] {
       checkNccl(api->groupStart(), "ncclGroupStart");
       for (int r = 0; r < world; ++r) {
         if (r == root || rowsOf(r) == 0) continue;

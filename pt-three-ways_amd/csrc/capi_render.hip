@@ -962,7 +962,9 @@ void renderMulti(const ptw_scene_view &scene, const ptw_camera &camera,
   // completion under the watchdog (ptw_comm_wait).  A shard whose call fails, or whose wait ends with
   // an asynchronous RCCL error or the timeout - a peer that never arrived -, aborts its communicator,
   // which releases the peers (loopback: the host rendezvous; RCCL: ncclCommAbort ends the kernels
-  // that wait for the missing peer on the device); after the join every communicator is aborted. ----
+  // that wait for the missing peer on the device) - and every other communicator with it, from the
+  // failing shard's own thread (ptw_comm_abort may be called while another thread waits on the
+  // communicator: that is what it is for). ----
   {
     std::vector<std::thread> threads;
     for (int g = 0; g < n; ++g)
@@ -984,8 +986,11 @@ void renderMulti(const ptw_scene_view &scene, const ptw_camera &camera,
           if (rc != PTW_OK) sh.error = ptw_last_error();
         }
         if (rc != PTW_OK) {
+          // this shard's collective failed: give up on EVERY communicator at once, so that the healthy
+          // shards' waits end now ("communicator aborted") and not at the watchdog's deadline - on the RCCL
+          // path aborting one rank does not release its peers
           sh.status = rc;
-          (void)ptw_comm_abort(comms[g]);
+          abortAll();
         }
       });
     for (auto &t : threads) t.join();

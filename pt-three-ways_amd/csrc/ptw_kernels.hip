@@ -692,9 +692,10 @@ struct SeqCtx {
     // a 64-lane reduction.
     const unsigned long long cands = __builtin_amdgcn_ballot_w64(bestIdx != kMiss);
     const int ncand = __builtin_popcountll(cands);
-    // Only the sign test `det < epsilon` of the winner's determinant is ever used: it travels as
-    // bit 31 of the index word, which saves the two cross-lane reads of the determinant (a
-    // v_readlane with a computed lane costs a lone wave four issue slots).
+    // Only the sign test `det < epsilon` of the winner's determinant is ever used: inside this function
+    // it travels as bit 31 of the index word (the answers exchanged BETWEEN waves carry it in bit 0:
+    // packAnswer), which saves the two cross-lane reads of the determinant (a v_readlane with a computed
+    // lane costs a lone wave four issue slots).
     const uint32_t packed = bestIdx | (bestDet < kEpsilon ? 0x80000000u : 0u);
     uint32_t pw;
     if (ncand == 0) {

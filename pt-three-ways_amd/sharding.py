@@ -116,5 +116,10 @@ class FrameComm:
         (ptw_comm_wait): a peer that died after its enqueue is an error, not a hang."""
         self.comm.wait(stream, timeout_ms)
 
+    def describe(self) -> dict:
+        """Which wire the collectives use (ptw_comm_describe): HIP's link report, the transport RCCL should
+        pick, and what RCCL's own log names when it goes to a file."""
+        return self.comm.describe()
+
     def close(self):
         self.comm.close()

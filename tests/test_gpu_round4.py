@@ -58,6 +58,12 @@ def test_bench_gpus_2_launches_itself_two_ranks_on_one_gpu(pkg, tmp_path, policy
         pytest.skip("RCCL refused two ranks on one GPU despite NCCL_HOSTID: " + proc.stderr[-800:])
     two = _line(proc)
     assert two["n_gpus"] == 2 and two["rccl_ranks"] == 2 and two["scaling"] == "strong"
+    # which wire: two ranks on ONE GPU pose as two hosts (NCCL_HOSTID) with P2P and SHM switched off - the
+    # line has to say so, from the environment AND from RCCL's own log (round 5; on an 8-GPU node the same
+    # field reads P2P/xGMI)
+    wire = two["rccl_transport"]
+    assert wire["p2p_disabled"] is True and wire["expected"] == "NET/Socket", wire
+    assert wire["rccl_log"] is None or any("NET/Socket" in t for t in wire["rccl_log"]), wire
     assert two["config"]["spp_this_rank"] == (6 if policy == "sequential" else 12)
     exp = two["scaling_expected"]
     assert exp["value_policy"] == policy and exp["sequential"]["passes_per_gpu"] == 6

@@ -88,3 +88,41 @@ def test_baseline_cfg1_shape(pkg, ob, tmp_path):
                       "--raw", "--save-every", "0", str(tmp_path / "cfg1.raw")], ROOT)
     raw_rgb, raw_cnt = pkg.raw_load(tmp_path / "cfg1.raw")
     assert np.array_equal(raw_cnt, ref_cnt) and np.array_equal(raw_rgb, rgb)
+
+
+MISSING_RANK_SCRIPT = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+import torch  # noqa: F401
+import __graft_entry__ as entry
+pkg = entry.load_package()
+uid = pkg.Comm.unique_id()
+t0 = time.time()
+try:
+    pkg.Comm.create(uid, 2, 0, 0)      # a world of two; rank 1 never calls
+    print("NO_ERROR")
+except pkg.PtwError as e:
+    print("INIT_GAVE_UP status", e.status, "after %.1f s:" % (time.time() - t0), e, flush=True)
+os._exit(0)                            # (the abandoned helper thread is still inside ncclCommInitRank)
+"""
+
+
+def test_communicator_setup_with_a_missing_rank_is_an_error_not_a_hang(tmp_path):
+    """ncclCommInitRank waits until every rank of the world has called it - a rank that
+    never arrives used to hang the others' set-up for ever, outside every later watchdog.  ptw_comm_create
+    now runs it under the collectives' deadline (PTW_COLLECTIVE_TIMEOUT_S) and returns PTW_ERR_HIP."""
+    script = tmp_path / "missing.py"
+    script.write_text(MISSING_RANK_SCRIPT.format(root=str(ROOT)))
+    env = dict(os.environ, PTW_COLLECTIVE_TIMEOUT_S="6", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_DEBUG="WARN",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=120)
+    assert "INIT_GAVE_UP status 3" in proc.stdout and "did not return within the timeout" in proc.stdout, \
+        proc.stdout[-800:] + proc.stderr[-1500:]
+
+
+def test_loopback_communicator_describes_itself(pkg):
+    comms = pkg.Comm.create_loopback(2, 0)
+    d = comms[1].describe()
+    assert d["kind"] == "loopback" and d["world"] == 2 and d["rank"] == 1 and d["rccl_log"] is None
+    for c in comms:
+        c.close()
