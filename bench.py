@@ -563,9 +563,9 @@ def main():
         # so that the line can say which wire the framebuffer collective crossed (`rccl_transport`): RCCL
         # names its transports in its INFO log - to a per-process file, not the terminal (read when the
         # first RCCL communicator of the process is made, i.e. below)
-        os.environ.setdefault("NCCL_DEBUG", "INFO")
-        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,P2P,NET,SHM")
-        os.environ.setdefault("NCCL_DEBUG_FILE", f"/tmp/ptw_bench_rccl_{os.getpid()}_%h_%p.log")
+        if "NCCL_DEBUG" not in os.environ and "NCCL_DEBUG_FILE" not in os.environ:
+            os.environ["NCCL_DEBUG"] = "INFO"
+            os.environ["NCCL_DEBUG_FILE"] = f"/tmp/ptw_bench_rccl_{os.getpid()}_%h_%p.log"
     # launched by torch.distributed.run (even with one rank): one process per GPU
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -588,16 +588,15 @@ int ptw_comm_describe(ptw_comm *comm, char *out, size_t capacity) {
       std::ifstream in(file);
       std::string line;
       while (std::getline(in, line)) {
-        haveLog = true;
         const size_t at = line.find(" via ");
         if (at == std::string::npos) continue;
         std::string word = line.substr(at + 5);
         const size_t end = word.find_first_of(" \t\r\n");
         if (end != std::string::npos) word.resize(end);
-        if (!word.empty() && word.size() < 48 && word.find('"') == std::string::npos) seen.insert(word);
+        if (!word.empty() && word.size() < 48 && word.find('"') == std::string::npos) seen.insert(word), haveLog = true;
       }
     }
-    if (!haveLog) {
+    if (!haveLog) { // no file, or one without channel lines (NCCL_DEBUG below INFO): RCCL did not say
       js << ", \"rccl_log\": null}";
     } else {
       js << ", \"rccl_log\": [";

@@ -847,9 +847,25 @@ struct SeqCtx {
   // candidates on - a 64-lane reduction.  PAIR: the answers of command slot `slot` (0 or 1).
   __device__ __forceinline__ HitKey pickPartials(int slot = 0) const {
     PartialHit ph[WAVES];
-    const PartialHit *src = partials + slot * WAVES;
+    // One ds_read_b128 per answer, all issued before the first is used (copied member by member the
+    // compiler reads 8 + 4 bytes each - twelve LDS instructions for six answers): the
+    // empty asm statement makes all four dwords of every answer count as used.
+    typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+    const U4 *src = reinterpret_cast<const U4 *>(partials + slot * WAVES);
+    static_assert(WAVES == 1 || WAVES == 6 || WAVES == 7, "six or seven worker waves");
+    U4 raw[WAVES];
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) ph[w] = src[w];
+    for (int w = 0; w < WAVES; ++w) raw[w] = src[w];
+    if constexpr (WAVES == 6)
+      asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]));
+    if constexpr (WAVES == 7)
+      asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]));
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      ph[w].t = mk64(static_cast<int>(raw[w].x), static_cast<int>(raw[w].y));
+      ph[w].idxSign = raw[w].z;
+      ph[w].pad = 0;
+    }
     return pickOfAnswers(ph);
   }
 

@@ -53,7 +53,7 @@ def test_bench_gpus_2_launches_itself_two_ranks_on_one_gpu(pkg, tmp_path, policy
     one = _line(_bench([*SMALL, "--policy", policy, "--dump-raw", one_raw], {}))
     assert one["n_gpus"] == 1 and one["rccl_ranks"] == 1 and "scaling_expected" not in one
     proc = _bench([*SMALL, "--gpus", "2", "--policy", policy, "--dump-raw", two_raw],
-                  {"PTW_BENCH_SHARE_GPU": "1", "NCCL_DEBUG": "WARN", "PTW_COLLECTIVE_TIMEOUT_S": "120"})
+                  {"PTW_BENCH_SHARE_GPU": "1", "PTW_COLLECTIVE_TIMEOUT_S": "120"})
     if proc.returncode != 0 and "Duplicate GPU detected" in proc.stderr:
         pytest.skip("RCCL refused two ranks on one GPU despite NCCL_HOSTID: " + proc.stderr[-800:])
     two = _line(proc)

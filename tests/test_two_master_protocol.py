@@ -1,8 +1,10 @@
-"""CPU models of the two protocols of the two-master worker kernel
+"""CPU models of the barrier protocols of the two-master worker kernel
 (pt-three-ways_amd/csrc/ptw_kernels.hip: SeqCtx<..., MASTERS = 2>::intersect / workerLoop /
-stopWorkers and the role set-up in traceSequential): the DECOUPLED protocol of round 4 (the default:
-request numbers and answer numbers in LDS, no workgroup barrier on the ray path - second half of this
-file) and round 2's LOCK STEP (-DPTW_SEQ_DECOUPLED=0, kept for A/B runs - first half).
+stopWorkers and the role set-up in traceSequential): the LOCK STEP the shipped kernels run (round 2's;
+first half of this file), and the PAIRED form of the experiments build (csrc/experiments/ptw_pair.h,
+round 5: one barrier per tick, the two command slots of BOTH masters searched alternately as one
+two-ray request - second half).  (Round 4's decoupled protocol - request and answer numbers in LDS, no
+barrier - left the tree in round 5 with its model; last revision 916a1dc.)
 
 Lock step:
 
@@ -180,119 +182,132 @@ def test_slot_major_assignment_gives_the_empty_slots_to_the_waves_beside_a_maste
             assert max(load[w] for w in shared) <= min(load[w] for w in ranks if w not in shared)
 
 
-# ---- the decoupled protocol (PTW_SEQ_DECOUPLED = 1) ------------------------------------------------
-# Every wave is a generator that yields between any two of its LDS accesses whose order matters; the
-# scheduler runs ONE step of ONE wave at a time, in an order a seeded generator picks - every
-# interleaving the hardware could produce of in-order LDS streams is a possible schedule here.  The
-# rules the kernel relies on: a writer stores its data BEFORE the number that announces it; a reader
-# loads the number BEFORE the data.
-DONE = 0xFFFFFFFF
-
-
-class Lds:
+# ---- the paired form (experiments build): one barrier per tick, command slots alternate -------------
+class PairGroup:
     def __init__(self):
-        self.op = [0, 0]                                     # SeqCommand::op: the request number
-        self.ray = [None, None]
-        self.answer = [[None] * WORKERS, [None] * WORKERS]   # PartialHit
-        self.flag = [[0] * WORKERS, [0] * WORKERS]           # number of the request the answer belongs to
-        self.searched = []                                   # (worker, master, ray)
-        self.reads = []                                      # (master, ray, answers)
-        self.done_at = {}                                    # wave -> scheduler step at which it left
+        self.op = [LIVE, LIVE]                      # SeqCommand::op
+        self.mask = [0, 0]                          # SeqCommand::nrays: bit c = slot c holds a ray
+        self.ray = [[None, None], [None, None]]     # [master][slot]
+        self.answers = [[[None] * WORKERS for _ in range(2)] for _ in range(2)]   # [master][slot][worker]
+        self.searched = []                          # (barrier, master, slot, ray id), logged by worker 0
+        self.reads = []                             # (master, slot, ray id, answers)
 
 
-def d_master(g, m, rays, has_pass):
+def pair_master(g, m, chains, has_pass):
+    """pairRun(): after barrier b the master works on slot c = (b + 1) & 1 - takes the answers of the ray
+    it put there two barriers ago, puts the next ray of that slot's chain in place (or leaves the slot
+    empty), updates bit c of its mask - while slot b & 1 of both masters is searched.  `chains`: per slot
+    the number of rays its chain traces in this pass (the model's stand-in for the path logic)."""
     if not has_pass:
-        g.op[m] = DONE          # (set in the prologue, before the workgroup's only __syncthreads)
-        return
-    seq = 0
-    for r in range(rays):
-        seq += 1
-        g.ray[m] = (m, r)       # the ray ...
-        yield
-        g.op[m] = seq           # ... then its number
-        yield                   # (flushPending / lookAhead: the master's own work)
-        while True:
-            got = list(g.flag[m])          # numbers first
-            yield
-            answers = list(g.answer[m])    # answers second
-            if all(f == seq for f in got):
-                break
-            yield               # s_sleep
-        g.reads.append((m, (m, r), answers))
-    g.op[m] = DONE
+        g.op[m] = 0
+        n = 0
+    else:
+        left = list(chains)
+        inflight = [None, None]
+        serial = 0
+        if left[0] > 0:                             # before barrier 0: the first ray, slot 0
+            g.ray[m][0] = inflight[0] = (m, 0, serial)
+            serial += 1
+            left[0] -= 1
+            g.mask[m] = 1
+        b = 0
+        more = inflight[0] is not None or left[1] > 0
+        if not more:
+            g.op[m] = 0
+        while more:
+            yield "B"                               # barrier b
+            c = (b + 1) & 1
+            if inflight[c] is not None and b > 0:
+                g.reads.append((m, c, inflight[c], list(g.answers[m][c])))
+                inflight[c] = None
+            bit = 0
+            if left[c] > 0:
+                g.ray[m][c] = inflight[c] = (m, c, serial)
+                serial += 1
+                left[c] -= 1
+                bit = 1
+            g.mask[m] = (g.mask[m] & ~(1 << c)) | (bit << c)
+            more = any(x is not None for x in inflight) or any(x > 0 for x in left)
+            if not more:
+                g.op[m] = b + 1                     # no rays from this master as of the next barrier
+            b += 1
+        n = b
+    while True:                                     # keep the cadence until the other one is done too
+        yield "B"
+        if g.op[0] <= n and g.op[1] <= n:
+            return
+        n += 1
 
 
-def d_worker(g, w):
-    served = [0, 0]
-    prefer = 0
+def pair_worker(g, w):
+    """workerLoopPair(): barrier n is followed by the search of slot n & 1 of both masters."""
+    n = 0
     while True:
-        s = [g.op[0], g.op[1]]             # numbers first
-        yield
-        rays = [g.ray[0], g.ray[1]]        # rays second
-        new = [s[i] != served[i] and s[i] not in (0, DONE) for i in (0, 1)]
-        if not (new[0] or new[1]):
-            if s[0] == DONE and s[1] == DONE:
-                return
-            yield                          # s_sleep
-            continue
-        m = prefer if (new[0] and new[1]) else (1 if new[1] else 0)
-        yield                              # the search
-        g.searched.append((w, m, rays[m]))
-        g.answer[m][w] = (rays[m], w)      # the answer ...
-        yield
-        g.flag[m][w] = s[m]                # ... then its number
-        served[m] = s[m]
-        prefer = m ^ 1
+        yield "B"
+        if g.op[0] <= n and g.op[1] <= n:
+            return
+        c = n & 1
+        for m in (0, 1):
+            if g.op[m] > n and (g.mask[m] >> c) & 1:
+                g.answers[m][c][w] = (g.ray[m][c], w)
+                if w == 0:
+                    g.searched.append((n, m, c, g.ray[m][c]))
+        n += 1
 
 
-def d_run(rays0, rays1, has1, seed, starve=None):
-    """`starve`: a wave the scheduler does not run while any other wave can make progress towards its
-    own end (None: fair).  Starving master 1 shows that master 0 does not wait for it."""
-    rnd = random.Random(seed)
-    g = Lds()
-    waves = {"m0": d_master(g, 0, rays0, True), "m1": d_master(g, 1, rays1, has1)}
-    waves.update({f"w{w}": d_worker(g, w) for w in range(WORKERS)})
-    live = list(waves)
-    for step in range(400 * (rays0 + rays1 + 2)):
+def run_pair(chains0, chains1, has1=True, order_seed=None):
+    rnd = random.Random(order_seed) if order_seed is not None else None
+    g = PairGroup()
+    waves = [pair_master(g, 0, chains0, True), pair_master(g, 1, chains1, has1)] + [pair_worker(g, w) for w in range(WORKERS)]
+    live = list(range(len(waves)))
+    barriers = 0
+    left_at = {}
+    for _ in range(20 * (sum(chains0) + sum(chains1)) + 40):
+        arrived, done = [], []
+        if rnd:
+            rnd.shuffle(live)
+        for i in live:
+            try:
+                next(waves[i])
+                arrived.append(i)
+            except StopIteration:
+                done.append(i)
+        for i in done:
+            left_at[i] = barriers
+        live = arrived
         if not live:
             break
-        pool = [n for n in live if n != starve] or live
-        if starve == "m1" and "m0" not in live:
-            pool = live                    # master 0 is through: let the starved one run
-        name = rnd.choice(pool)
-        try:
-            next(waves[name])
-        except StopIteration:
-            live.remove(name)
-            g.done_at[name] = step
-    assert not live, f"deadlock / livelock: {live} still running"
-    return g
+        assert not done or not live, f"waves {done} left at barrier {barriers} while {live} still wait"
+        barriers += 1
+    assert not live, "deadlock"
+    assert len(set(left_at.values())) == 1
+    return g, barriers
 
 
-def test_decoupled_protocol_all_ray_counts_and_schedules():
-    for rays0, rays1, has1 in itertools.product(range(0, 6), range(0, 6), (True, False)):
-        if not has1 and rays1:
+def test_paired_protocol_all_chain_lengths():
+    """Every ray a master puts into a slot is searched exactly once - by every worker, in the tick after
+    the barrier that follows it, together with the other master's ray of the same slot - and read back
+    with all six answers two barriers after it was placed; nobody deadlocks, everybody leaves after the
+    same barrier, whatever the two slots' chain lengths (an empty second slot, an empty pass, a master
+    without a pass) and whatever order the waves run in between barriers."""
+    lengths = [(a, b) for a in range(0, 5) for b in range(0, 4)]
+    for chains0, chains1, has1 in itertools.product(lengths, lengths, (True, False)):
+        if not has1 and sum(chains1):
             continue
-        expect = [(0, r) for r in range(rays0)] + ([(1, r) for r in range(rays1)] if has1 else [])
-        for seed in range(12):
-            g = d_run(rays0, rays1, has1, seed)
-            # every published ray searched by every worker exactly once ...
-            assert sorted(g.searched) == sorted((w, ray[0], ray) for ray in expect for w in range(WORKERS))
-            # ... and read by ITS master, in order, with the six answers of THAT ray
-            assert [ray for m, ray, _ in g.reads if m == 0] == [(0, r) for r in range(rays0)]
-            assert [ray for m, ray, _ in g.reads if m == 1] == ([(1, r) for r in range(rays1)] if has1 else [])
-            for m, ray, answers in g.reads:
-                assert answers == [(ray, w) for w in range(WORKERS)]
-            # the workers leave only after both masters are done
-            last_master = max(g.done_at["m0"], g.done_at["m1"])
-            assert all(g.done_at[f"w{w}"] > last_master for w in range(WORKERS))
-
-
-def test_decoupled_masters_do_not_wait_for_each_other():
-    """The point of the protocol: with master 1 not scheduled at all, master 0 traces every one of its
-    rays (in lock step it would sit at the first barrier master 1 does not reach)."""
-    for seed in range(8):
-        g = d_run(5, 4, True, seed, starve="m1")
-        assert g.done_at["m0"] < g.done_at["m1"]
-        first_m1_read = min(i for i, (m, _, _) in enumerate(g.reads) if m == 1)
-        assert [ray for m, ray, _ in g.reads[:first_m1_read]] == [(0, r) for r in range(5)]
+        g, barriers = run_pair(chains0, chains1, has1)
+        placed0 = sum(chains0) if chains0[0] > 0 or chains0[1] > 0 else 0
+        placed1 = (sum(chains1) if has1 else 0)
+        assert len([1 for _, m, _, _ in g.searched if m == 0]) == placed0
+        assert len([1 for _, m, _, _ in g.searched if m == 1]) == placed1
+        assert len(set(ray for _, _, _, ray in g.searched)) == len(g.searched)          # each exactly once
+        assert sorted(ray for _, _, ray, _ in g.reads) == sorted(ray for _, _, _, ray in g.searched)
+        for m, c, ray, answers in g.reads:
+            assert answers == [(ray, w) for w in range(WORKERS)]
+        for n, m, c, ray in g.searched:
+            assert n & 1 == c                                                             # slots alternate
+        # one ray per slot and two barriers: the longer slot of the longer pass sets the length
+        longest = max(2 * max(chains0[0] - 0, 0), 2 * chains0[1] + 1, 2 * chains1[0] if has1 else 0, (2 * chains1[1] + 1) if has1 else 0)
+        assert barriers <= longest + 4
+        for seed in range(4):
+            g2, b2 = run_pair(chains0, chains1, has1, order_seed=seed)
+            assert b2 == barriers and sorted(g2.searched) == sorted(g.searched) and sorted(g2.reads) == sorted(g.reads)
