@@ -16,5 +16,5 @@ for k, c, v in rows:
     if 'trace' in k:
         d.setdefault(k.split('(')[0][-40:], {})[c] = v
 for k, c in d.items():
-    print(k, {a: f"{b:.4g}" for a, b in c.items()})
+    print(k, {a: f"{b:.6g}" for a, b in c.items()})
 PY

@@ -8,9 +8,13 @@ pkg = e.load_package()
 def run(name, w, h, spp, policy, debug):
     scene = pkg.Scene(); cam = scene.build_named(name, w, h)
     ctx = pkg.Context(0); ctx.set_scene(scene); ctx.enable_stats(True)
+    extra = {}
+    if "pix_kernel" in debug:   # (a ptw_render_params field, not a debug option: 1 lock-step, 2 persistent)
+        debug = dict(debug)
+        extra["pix_kernel"] = debug.pop("pix_kernel")
     if debug:
         ctx.set_debug(**debug)
-    params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=1, rng_policy=policy)
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=1, rng_policy=policy, **extra)
     rgb = torch.zeros((h, w, 3), dtype=torch.float64, device='cuda'); cnt = torch.zeros((h, w), dtype=torch.int32, device='cuda')
     st = torch.cuda.current_stream().cuda_stream
     torch.cuda.synchronize(); t = time.time()
