@@ -98,3 +98,13 @@ def test_product_does_not_link_or_reference_the_oracle(pkg):
         if path.suffix in {".cpp", ".h", ".hip", ".py"} and path.is_file():
             text = path.read_text()
             assert "oracle/" not in text.replace("see oracle/ptw_oracle.c for the definition", ""), path
+
+
+def test_abi_version_is_the_same_everywhere(pkg):
+    """include/ptw.h, the library and the driver's build check (__graft_entry__.build) agree on the ABI
+    version (round 5: the build check still asked for 4 after the header went to 5)."""
+    import re
+    from conftest import ROOT
+    header = int(re.search(r"#define PTW_ABI_VERSION (\d+)", (ROOT / "include" / "ptw.h").read_text()).group(1))
+    assert pkg.lib.ptw_abi_version() == header
+    assert f"ptw_abi_version() == {header}" in (ROOT / "__graft_entry__.py").read_text()
