@@ -6,7 +6,10 @@
 // is within the reference's own build-to-build spread (its CMakeLists.txt:21 builds with
 // -march=native -funsafe-math-optimizations, i.e. with FMA contraction), and parity is
 // asserted to 1e-12 relative with bit-exact RNG word counts (tests/test_gpu_parity.py).
-// sqrt and division are IEEE correctly rounded on gfx950 (no fast-math flags are used).
+// Division and square roots are NOT the IEEE sequences by default: v_rcp_f64 / v_rsq_f64 seeds refined by
+// two Newton steps (PTW_FAST_MATH below, about 1 ulp; -DPTW_FAST_MATH=0 restores the correctly rounded
+// operations, `make ieee`); no compiler fast-math flag is used.  DESIGN.md section 4 says what either
+// deviation can and cannot change.
 #pragma once
 
 #include <hip/hip_runtime.h>
