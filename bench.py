@@ -563,7 +563,9 @@ def main():
         # so that the line can say which wire the framebuffer collective crossed (`rccl_transport`): RCCL
         # names its transports in its INFO log - to a per-process file, not the terminal (read when the
         # first RCCL communicator of the process is made, i.e. below)
-        if "NCCL_DEBUG" not in os.environ and "NCCL_DEBUG_FILE" not in os.environ:
+        # (a level below INFO - some hosts export VERSION or WARN - has no channel lines: raised, and the file
+        # keeps RCCL's text off the terminal either way; an explicit INFO / TRACE or file is the caller's)
+        if "NCCL_DEBUG_FILE" not in os.environ and os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION", "WARN"):
             os.environ["NCCL_DEBUG"] = "INFO"
             os.environ["NCCL_DEBUG_FILE"] = f"/tmp/ptw_bench_rccl_{os.getpid()}_%h_%p.log"
     # launched by torch.distributed.run (even with one rank): one process per GPU
@@ -706,6 +708,7 @@ def main():
                 d = shard.comm.describe()
                 links = sorted({ln["type"] for ln in d.get("links", [])})
                 result["rccl_transport"] = {"expected": d.get("expected"), "rccl_log": d.get("rccl_log"),
+                                            "rccl_log_file": d.get("rccl_log_file"),
                                             "link_types_from_gpu0": links, "p2p_disabled": d.get("p2p_disabled")}
             except Exception as e:  # noqa: BLE001
                 result["rccl_transport"] = {"error": repr(e)[:200]}

@@ -596,6 +596,9 @@ int ptw_comm_describe(ptw_comm *comm, char *out, size_t capacity) {
         if (!word.empty() && word.size() < 48 && word.find('"') == std::string::npos) seen.insert(word), haveLog = true;
       }
     }
+    js << ", \"rccl_log_file\": ";
+    if (file.empty()) js << "null";
+    else js << "\"" << (file.find_first_of("\"\\") == std::string::npos ? file : std::string("(unprintable)")) << "\"";
     if (!haveLog) { // no file, or one without channel lines (NCCL_DEBUG below INFO): RCCL did not say
       js << ", \"rccl_log\": null}";
     } else {

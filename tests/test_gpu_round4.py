@@ -63,7 +63,9 @@ def test_bench_gpus_2_launches_itself_two_ranks_on_one_gpu(pkg, tmp_path, policy
     # field reads P2P/xGMI)
     wire = two["rccl_transport"]
     assert wire["p2p_disabled"] is True and wire["expected"] == "NET/Socket", wire
-    assert wire["rccl_log"] is None or any("NET/Socket" in t for t in wire["rccl_log"]), wire
+    # (the bench raises NCCL_DEBUG from the box's VERSION to INFO into a file of its own, so RCCL does say)
+    assert wire["rccl_log"] and any("NET/Socket" in t for t in wire["rccl_log"]), wire
+    assert wire["rccl_log_file"], wire
     assert two["config"]["spp_this_rank"] == (6 if policy == "sequential" else 12)
     exp = two["scaling_expected"]
     assert exp["value_policy"] == policy and exp["sequential"]["passes_per_gpu"] == 6
