@@ -26,8 +26,9 @@ pytestmark = pytest.mark.gpu
 
 def _bench(args, env_extra, timeout=600):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NCCL_DEBUG_FILE"):
         env.pop(k, None)
+    env["NCCL_DEBUG"] = "VERSION"   # (what the GPU boxes export; the bench raises it for its own log file)
     proc = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True,
                           timeout=timeout, cwd=ROOT, env=env)
     return proc
