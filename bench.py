@@ -550,6 +550,19 @@ def strict_leg(args):
     }
 
 
+def route_rccl_log(env):
+    """So that the line can say which wire the framebuffer collective crossed (`rccl_transport`): RCCL names
+    its transports in its INFO log - sent to a per-process file, not the terminal (RCCL reads these variables
+    when the first communicator of the process is made).  A level below INFO - the GPU boxes export VERSION -
+    has no channel lines: raised.  An explicit INFO / TRACE or a file of the caller's own is left alone.
+    Returns True when it took the log over."""
+    if "NCCL_DEBUG_FILE" in env or env.get("NCCL_DEBUG", "").upper() not in ("", "VERSION", "WARN"):
+        return False
+    env["NCCL_DEBUG"] = "INFO"
+    env["NCCL_DEBUG_FILE"] = f"/tmp/ptw_bench_rccl_{os.getpid()}_%h_%p.log"
+    return True
+
+
 def main():
     args = parse_args()
     use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
@@ -560,14 +573,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     device = device_of(local_rank, rank)
     if use_dist and world > 1:
-        # so that the line can say which wire the framebuffer collective crossed (`rccl_transport`): RCCL
-        # names its transports in its INFO log - to a per-process file, not the terminal (read when the
-        # first RCCL communicator of the process is made, i.e. below)
-        # (a level below INFO - some hosts export VERSION or WARN - has no channel lines: raised, and the file
-        # keeps RCCL's text off the terminal either way; an explicit INFO / TRACE or file is the caller's)
-        if "NCCL_DEBUG_FILE" not in os.environ and os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION", "WARN"):
-            os.environ["NCCL_DEBUG"] = "INFO"
-            os.environ["NCCL_DEBUG_FILE"] = f"/tmp/ptw_bench_rccl_{os.getpid()}_%h_%p.log"
+        route_rccl_log(os.environ)
     # launched by torch.distributed.run (even with one rank): one process per GPU
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -96,3 +96,23 @@ def test_ref_passes_runs_the_restatement_when_the_reference_is_absent(bench, pkg
         rad_r, words_r = rs.render_pass(desc, prefix, 1)
         assert np.array_equal(rad_r[:3], seen[1][1][:3]) and np.array_equal(words_r[:3], seen[1][2][:3])
         assert not rad_r[3:].any()
+
+
+@pytest.mark.parametrize("env,taken", [
+    ({}, True),                                    # nothing set
+    ({"NCCL_DEBUG": "VERSION"}, True),             # what the GPU boxes export: no channel lines at that level
+    ({"NCCL_DEBUG": "warn"}, True),
+    ({"NCCL_DEBUG": "INFO"}, False),               # the caller's own choice of level ...
+    ({"NCCL_DEBUG": "TRACE"}, False),
+    ({"NCCL_DEBUG_FILE": "/tmp/mine.log"}, False),                       # ... or of a file is left alone
+    ({"NCCL_DEBUG": "VERSION", "NCCL_DEBUG_FILE": "/tmp/mine.log"}, False),
+])
+def test_rccl_log_is_routed_to_a_file_unless_the_caller_chose(bench, env, taken):
+    """`rccl_transport.rccl_log` needs RCCL's INFO channel lines in a file ptw_comm_describe can read
+    (round 5: the first two-rank line said null because the box exports NCCL_DEBUG=VERSION)."""
+    before = dict(env)
+    assert bench.route_rccl_log(env) is taken
+    if taken:
+        assert env["NCCL_DEBUG"] == "INFO" and "%h" in env["NCCL_DEBUG_FILE"] and "%p" in env["NCCL_DEBUG_FILE"]
+    else:
+        assert env == before
