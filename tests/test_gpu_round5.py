@@ -5,7 +5,9 @@
   measured slower than round 4's lock step, so it lives in the experiments build and is
   held to the oracle there, in a child process: every instantiation, the BASELINE scenes, exact ties, the
   natural dispatch - radiance sums, every sample's RNG word count and pick checksum;
-* BASELINE cfg1's exact shape (cornell 256 x 256 @ 8 spp, seed 1) through the C ABI and through the CLI.
+* BASELINE cfg1's exact shape (cornell 256 x 256 @ 8 spp, seed 1) through the C ABI and through the CLI;
+* the tile-shardable policy at the frame the metric is quoted on: both PERPIXEL kernels, the whole 1024 x 1024
+  frame, against the oracle.
 """
 import os
 import subprocess
@@ -126,3 +128,44 @@ def test_loopback_communicator_describes_itself(pkg):
     assert d["kind"] == "loopback" and d["world"] == 2 and d["rank"] == 1 and d["rccl_log"] is None
     for c in comms:
         c.close()
+
+
+@pytest.fixture(scope="module")
+def perpixel_headline_reference(pkg, ob):
+    """The oracle's 1024 x 1024 x 2 PERPIXEL frame, once for both kernels (half a minute of host work)."""
+    scene = pkg.Scene()
+    cam = scene.build_named("cornell", 1024, 1024)
+    params = pkg.default_params(width=1024, height=1024, samples_per_pixel=2, seed=1, rng_policy=pkg.RNG_PERPIXEL)
+    return ob.oracle_render(scene.view(), cam, params, threads=2)
+
+
+@pytest.mark.parametrize("kernel", ["lockstep", "persistent"])
+def test_full_headline_frame_under_the_perpixel_policy_matches_oracle(pkg, perpixel_headline_reference, kernel):
+    """cornell 1024 x 1024 - the frame BASELINE.json's metric is quoted on - under the PERPIXEL policy (the one
+    `value_tile_sharded` and north_star's image tiling are about), 2 passes, each of the policy's two kernels:
+    every pixel's fp64 sum and every sample's RNG word count against the oracle's restatement of the same
+    policy.  (tests/test_gpu_round2.py holds the SEQUENTIAL policy to the same frame; until round 5 the largest
+    PERPIXEL frame compared was 64 x 64.)"""
+    import torch
+    w = h = 1024
+    scene = pkg.Scene()
+    cam = scene.build_named("cornell", w, h)
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=2, seed=1, rng_policy=pkg.RNG_PERPIXEL,
+                                pix_kernel=pkg.PIX_KERNEL_LOCKSTEP if kernel == "lockstep" else pkg.PIX_KERNEL_PERSISTENT)
+    ref_rgb, ref_cnt, ref_words, _ = perpixel_headline_reference
+    ctx = pkg.Context(0)
+    ctx.set_scene(scene)
+    ctx.enable_stats(True)
+    rgb = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+    cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    words = torch.zeros((2, h, w), dtype=torch.int32, device="cuda")
+    ctx.render(cam, params, rgb.data_ptr(), cnt.data_ptr(), words.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    variant = ctx.stats(reset=True).trace_kernel.decode()
+    assert variant.startswith("tracePerPixel") and (kernel == "persistent") == ("Persistent" in variant), variant
+    rgb, cnt, words = rgb.cpu().numpy(), cnt.cpu().numpy().astype(np.uint32), words.cpu().numpy().astype(np.uint32)
+    assert np.array_equal(cnt, ref_cnt)
+    assert int(np.count_nonzero(words != ref_words)) == 0, "a path decision diverged somewhere in the frame"
+    scale = np.maximum(np.abs(ref_rgb), 1.0)
+    assert float(np.max(np.abs(rgb - ref_rgb) / scale)) < 1e-12
+    assert np.all(rgb == ref_rgb, axis=2).mean() > 0.999
