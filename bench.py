@@ -189,7 +189,13 @@ def self_launch(args):
         port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    # HSA_ENABLE_IPC_MODE_LEGACY: which IPC path ROCr offers RCCL's P2P transport.  The hosts this was built on
+    # support dmabuf IPC only (0) - with the legacy mode hipIpcGetMemHandle fails with "invalid argument" - and
+    # export the variable themselves.  The caller's value is kept as it is; only an environment WITHOUT it gets
+    # the 0 that is known to work here (`rccl_transport.hsa_enable_ipc_mode_legacy` in the
+    # line says what the ranks ran with; scripts/first_contact_8gpu.sh probes both values on a new node).
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     sys.exit(subprocess.call(cmd, env=env))
 
 
@@ -560,6 +566,16 @@ def route_rccl_log(env):
         return False
     env["NCCL_DEBUG"] = "INFO"
     env["NCCL_DEBUG_FILE"] = f"/tmp/ptw_bench_rccl_{os.getpid()}_%h_%p.log"
+    import atexit
+    import glob
+
+    def remove_logs(pattern=f"/tmp/ptw_bench_rccl_{os.getpid()}_*.log"):   # (read by describe() before exit)
+        for f in glob.glob(pattern):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+    atexit.register(remove_logs)
     return True
 
 
@@ -616,6 +632,14 @@ def main():
         shard.params.pix_kernel = agreed_pix_kernel(pkg, ctx, cam, shard.params, rank, use_dist, stream)
     if args.warmup > 0:
         timed_steps(shard, ctx, cam, [scratch], args.warmup, use_dist)
+    elif shard.comm is not None and world > 1:
+        # no warm-up step: RCCL connects its channels - and writes its INFO lines, when route_rccl_log took
+        # the log over - at the communicator's FIRST collective; that must not be the timed one
+        if shard.merge == "reduce":
+            shard.comm.reduce_framebuffer(scratch[0], scratch[1], dst=0, stream=stream)
+        else:
+            shard.comm.gather_rows(scratch[0], scratch[1], dst=0, stream=stream)
+        shard.comm.wait(stream)
     scratch[0].zero_()
     scratch[1].zero_()
 
@@ -713,8 +737,11 @@ def main():
             try:   # rank 0's view: its GPU's links, the transport that follows, RCCL's own channel lines
                 d = shard.comm.describe()
                 links = sorted({ln["type"] for ln in d.get("links", [])})
-                result["rccl_transport"] = {"expected": d.get("expected"), "rccl_log": d.get("rccl_log"),
+                result["rccl_transport"] = {"expected": d.get("expected"), "expected_is": d.get("expected_is"),
+                                            "rccl_log": d.get("rccl_log"), "rccl_log_scope": d.get("rccl_log_scope"),
                                             "rccl_log_file": d.get("rccl_log_file"),
+                                            "abandoned_setups": d.get("abandoned_setups"),
+                                            "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                                             "link_types_from_gpu0": links, "p2p_disabled": d.get("p2p_disabled")}
             except Exception as e:  # noqa: BLE001
                 result["rccl_transport"] = {"error": repr(e)[:200]}

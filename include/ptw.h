@@ -351,7 +351,11 @@ int ptw_context_rng_doubles(ptw_context *ctx, int32_t rng_policy, uint32_t seed,
 typedef struct ptw_comm ptw_comm;
 int ptw_comm_unique_id(uint8_t id_out[PTW_COMM_ID_BYTES]);
 /* (Both set-up calls give up with PTW_ERR_HIP after PTW_COLLECTIVE_TIMEOUT_S - default 300 s - when a
- * rank of the world never arrives; ncclCommInitRank would otherwise wait for it for ever.) */
+ * rank of the world never arrives; ncclCommInitRank would otherwise wait for it for ever.  The thread that
+ * made the RCCL call is then ABANDONED inside RCCL's bootstrap, with its sockets and its device context, for
+ * the rest of the process: treat the process as poisoned for multi-GPU work after this error - report it and
+ * restart rather than retry.  The library counts such threads (ptw_comm_describe: `abandoned_setups`) and
+ * refuses a fifth set-up attempt outright.) */
 int ptw_comm_create(const uint8_t id[PTW_COMM_ID_BYTES], int32_t world_size, int32_t rank,
                     int32_t device, ptw_comm **out);
 int ptw_comm_create_all(int32_t num_devices, const int32_t *devices, ptw_comm **out_comms);

@@ -127,33 +127,88 @@ std::chrono::milliseconds collectiveTimeout(int32_t timeoutMs = 0) {
 // timeout, the caller aborts the communicator from here - ncclCommAbort is the one RCCL call that
 // may be made while another thread is inside the library, and it is what unblocks that thread.
 // (The handle is an atomic: whoever exchanges it for null - this function's timeout path, or
-// ptw_comm_abort on another thread - is the one caller of ncclCommAbort; `guard` keeps that call apart
-// from ptw_comm_wait's ncclCommGetAsyncError on the same handle, which ncclCommAbort frees.)
+// ptw_comm_abort on another thread - is the one caller of ncclCommAbort; the gate's mutex keeps that call
+// apart from ptw_comm_wait's ncclCommGetAsyncError on the same handle, which ncclCommAbort frees.)
 // One helper thread per group of collective calls: a frame has ONE such group (the reduce or the gather
 // at its end, seconds to minutes of rendering apart), so the thread's few tens of microseconds do not show.
+//
+// Enqueue against abort.  ncclCommAbort FREES the handle, so a thread that is about to START a
+// group of calls on it must not meet an abort from another thread (ptw_render_ex: the shard whose collective
+// failed aborts every shard's communicator from its own thread, while the healthy shards may only just be
+// entering theirs).  `CallGate` makes the two exclusive without making the abort wait for a call that is
+// stuck: the enqueuing thread takes the handle and marks the communicator "in a call" under the guard; an
+// abort that arrives meanwhile leaves a request and waits a short grace period for the call to return - the
+// normal case, an enqueue takes microseconds to milliseconds - after which the thread that made the call
+// aborts its own communicator; only a call that is still inside RCCL after the grace period (it waits for
+// a peer on the host) is aborted from outside, which is what ncclCommAbort is documented for.
+struct CallGate {
+  std::mutex m;                 // also keeps ncclCommAbort apart from ptw_comm_wait's ncclCommGetAsyncError
+  std::condition_variable cv;
+  bool inCall = false;          // a group of RCCL calls is being made on the handle
+  bool abortRequested = false;  // ... and somebody wants the communicator gone when it returns
+};
+constexpr std::chrono::milliseconds kAbortGrace(2000);
+
+// The one place that calls ncclCommAbort.  `fromCaller`: the thread that owns the in-flight call.
+// Returns the abort's result (ncclSuccess when there was nothing left to abort).
+ncclResult_t abortHandle(std::atomic<ncclComm_t> &comm, CallGate &gate, bool fromCaller) {
+  std::unique_lock<std::mutex> lock(gate.m);
+  if (!fromCaller && gate.inCall) {
+    gate.abortRequested = true;
+    if (gate.cv.wait_for(lock, kAbortGrace, [&] { return !gate.inCall; })) {
+      // the call returned; its thread has aborted (or will find the request under this mutex) - nothing
+      // is in flight on the handle now, so finishing the job here is safe either way
+    }
+  }
+  ncclResult_t r = ncclSuccess;
+  if (const ncclComm_t c = comm.exchange(nullptr)) r = rccl().commAbort(c);
+  return r;
+}
+
 template <typename Body>
-void runAbortable(std::atomic<ncclComm_t> &comm, std::mutex &guard, int device, const char *what, Body &&body) {
+void runAbortable(std::atomic<ncclComm_t> &comm, CallGate &gate, int device, const char *what, Body &&body) {
+  ncclComm_t nc = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(gate.m);
+    nc = comm.load();
+    if (nc) gate.inCall = true;
+  }
+  if (!nc) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
+  auto leave = [&]() { // the call is over: wake an abort that waits for it; true if one was requested
+    std::lock_guard<std::mutex> lock(gate.m);
+    gate.inCall = false;
+    const bool wanted = gate.abortRequested;
+    gate.cv.notify_all();
+    return wanted;
+  };
   std::promise<void> done;
   std::future<void> fut = done.get_future();
   std::thread helper([&] {
     try {
       checkHip(hipSetDevice(device), "hipSetDevice");
-      body();
+      body(nc);
       done.set_value();
     } catch (...) {
       done.set_exception(std::current_exception());
     }
   });
   if (fut.wait_for(collectiveTimeout()) != std::future_status::ready) {
+    // still inside RCCL at the deadline (a peer that never arrived): abort under the call - the one RCCL
+    // call that may be made while another thread is inside the library, and what unblocks that thread
     {
-      std::lock_guard<std::mutex> lock(guard);
+      std::lock_guard<std::mutex> lock(gate.m);
       if (const ncclComm_t c = comm.exchange(nullptr)) (void)rccl().commAbort(c);
     }
     helper.join();
+    (void)leave();
     throw DeviceError(PTW_ERR_HIP, std::string(what) + " did not return within the timeout (a peer that never "
                                        "arrived?): communicator aborted");
   }
   helper.join();
+  if (leave()) {
+    (void)abortHandle(comm, gate, true);
+    throw DeviceError(PTW_ERR_HIP, "communicator aborted");
+  }
   fut.get();
 }
 
@@ -170,8 +225,20 @@ struct InitState {
   std::exception_ptr error;
   std::vector<ncclComm_t> comms;
 };
+// Every abandoned set-up leaves a thread inside ncclCommInitRank with its bootstrap sockets for the rest of
+// the process: counted (ptw_comm_describe: `abandoned_setups`) and capped - a host that keeps
+// retrying against a world that never assembles is told to restart instead of leaking a thread per attempt.
+constexpr int kMaxAbandonedInits = 4;
+std::atomic<int> &abandonedInits() {
+  static std::atomic<int> n{0};
+  return n;
+}
 template <typename Body>
 std::vector<ncclComm_t> runInitAbortable(const char *what, Body body) {
+  if (abandonedInits().load() >= kMaxAbandonedInits)
+    throw DeviceError(PTW_ERR_HIP, std::string(what) + ": " + std::to_string(kMaxAbandonedInits) +
+                                       " earlier communicator set-ups of this process were given up at their deadline and "
+                                       "their threads are still inside RCCL's bootstrap - restart the process");
   auto state = std::make_shared<InitState>();
   std::thread helper([state, body] {
     std::vector<ncclComm_t> made;
@@ -198,6 +265,7 @@ std::vector<ncclComm_t> runInitAbortable(const char *what, Body body) {
     state->abandoned = true;
     lock.unlock();
     helper.detach();
+    abandonedInits().fetch_add(1);
     throw DeviceError(PTW_ERR_HIP, std::string(what) + " did not return within the timeout (PTW_COLLECTIVE_TIMEOUT_S; a rank "
                                        "that never called it?): communicator set-up given up");
   }
@@ -270,7 +338,7 @@ using namespace ptw;
 
 struct ptw_comm {
   std::atomic<ncclComm_t> comm{nullptr}; // RCCL transport (null once aborted: see runAbortable)
-  std::mutex guard;                       // ncclCommAbort (frees the handle) against ncclCommGetAsyncError on it
+  CallGate gate;                          // enqueue / ncclCommGetAsyncError against ncclCommAbort (frees the handle)
   std::shared_ptr<LoopbackHub> hub;   // loopback transport (comm == nullptr)
   // loopback: one `ready` event per (destination, channel) and one `consumed` event per (source,
   // channel), created on first use and re-recorded for every message - a long-lived communicator
@@ -443,11 +511,9 @@ int ptw_comm_abort(ptw_comm *comm) {
   if (comm->hub) {
     comm->hub->abort();
   } else {
-    std::lock_guard<std::mutex> lock(comm->guard); // (not while ptw_comm_wait looks at the handle)
-    if (const ncclComm_t c = comm->comm.exchange(nullptr)) {
-      // ncclCommAbort frees the communicator: kernels of it that wait for a peer on the device end
-      checkNccl(rccl().commAbort(c), "ncclCommAbort");
-    }
+    // ncclCommAbort frees the communicator: kernels of it that wait for a peer on the device end.  Not
+    // while ptw_comm_wait looks at the handle, and not while another thread is STARTING calls on it (CallGate)
+    checkNccl(abortHandle(comm->comm, comm->gate, false), "ncclCommAbort");
   }
   return PTW_OK;
   PTW_GUARD_END
@@ -483,7 +549,7 @@ int ptw_comm_wait(ptw_comm *comm, void *hip_stream, int32_t timeout_ms) {
       ncclResult_t r = ncclSuccess, async = ncclSuccess;
       bool gone = false;
       {
-        std::lock_guard<std::mutex> lock(comm->guard);
+        std::lock_guard<std::mutex> lock(comm->gate.m);
         if (const ncclComm_t nc = comm->comm.load())
           r = rccl().commGetAsyncError(nc, &async);
         else
@@ -516,9 +582,9 @@ const char *linkTypeName(uint32_t t) {
   default: return "unknown";
   }
 }
-bool envIsOne(const char *name) {
+bool envIsOne(const char *name) { // RCCL reads these as integers: any non-zero value switches the transport off
   const char *v = std::getenv(name);
-  return v && v[0] == '1';
+  return v && *v && std::strtol(v, nullptr, 0) != 0;
 }
 // NCCL_DEBUG_FILE with RCCL's %h (host name) and %p (process id) filled in; empty: not set
 std::string rcclDebugFile() {
@@ -578,7 +644,11 @@ int ptw_comm_describe(ptw_comm *comm, char *out, size_t capacity) {
     const char *expected = p2pOff ? (shmOff ? "NET/Socket" : "SHM")
                                   : (!anyPeer ? "one visible GPU: the peers are other hosts to RCCL (NET)"
                                               : (allXgmi ? "P2P/xGMI" : "P2P (not every peer over xGMI: see links)"));
-    js << ", \"expected\": \"" << expected << "\"";
+    // (`expected` is a GUESS from HIP's link types and the two switches above: it does not know
+    // NCCL_P2P_LEVEL, HIP_VISIBLE_DEVICES orderings or worlds that span hosts - `rccl_log` is what RCCL says)
+    js << ", \"expected\": \"" << expected << "\", \"expected_is\": \"a guess from HIP link types and NCCL_P2P_DISABLE / NCCL_SHM_DISABLE\"";
+    js << ", \"rccl_log_scope\": \"every communicator of this process that logs to the file\"";
+    js << ", \"abandoned_setups\": " << abandonedInits().load();
     // ... and what RCCL says it chose, when its log goes to a file (NCCL_DEBUG=INFO, NCCL_DEBUG_FILE): the
     // transports named after "via" in its channel lines
     const std::string file = rcclDebugFile();
@@ -649,10 +719,10 @@ int ptw_comm_reduce_framebuffer(ptw_comm *comm, void *d_rgb_sum, void *d_counts,
     }
     return PTW_OK;
   }
-  const ncclComm_t nc = comm->comm.load();
-  if (!nc) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
   const Rccl &api = rccl();
-  runAbortable(comm->comm, comm->guard, comm->device, "ncclReduce of the framebuffer", [&] {
+  // (the handle is taken inside runAbortable, under the gate: an abort from another thread either comes
+  // first - "communicator aborted" - or waits for these calls to return)
+  runAbortable(comm->comm, comm->gate, comm->device, "ncclReduce of the framebuffer", [&](ncclComm_t nc) {
     // one group: both reductions are launched together
     checkNccl(api.groupStart(), "ncclGroupStart");
     checkNccl(api.reduce(d_rgb_sum, d_rgb_sum, npix * 3, ncclDouble, ncclSum, root, nc, stream),
@@ -676,8 +746,7 @@ int ptw_comm_gather_rows(ptw_comm *comm, void *d_rgb_sum, void *d_counts, int32_
   const int world = comm->world, rank = comm->rank;
   if (world == 1) return PTW_OK;
   const bool loop = static_cast<bool>(comm->hub);
-  const ncclComm_t nc = loop ? nullptr : comm->comm.load();
-  if (!loop && !nc) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
+  if (!loop && !comm->comm.load()) throw DeviceError(PTW_ERR_HIP, "communicator aborted");
   const Rccl *api = loop ? nullptr : &rccl();
   const size_t w = static_cast<size_t>(width);
   const size_t rgbRow = w * 3 * sizeof(double), cntRow = w * sizeof(uint32_t);
@@ -705,7 +774,7 @@ int ptw_comm_gather_rows(ptw_comm *comm, void *d_rgb_sum, void *d_counts, int32_
       }
       return PTW_OK;
     }
-    runAbortable(comm->comm, comm->guard, comm->device, "ncclSend of the rows", [&] {
+    runAbortable(comm->comm, comm->gate, comm->device, "ncclSend of the rows", [&](ncclComm_t nc) {
       checkNccl(api->groupStart(), "ncclGroupStart");
       if (rows) {
         checkNccl(api->send(packRgb, rows * w * 3, ncclDouble, root, nc, stream), "ncclSend(rgb)");
@@ -730,7 +799,7 @@ int ptw_comm_gather_rows(ptw_comm *comm, void *d_rgb_sum, void *d_counts, int32_
       });
     }
   } else {
-    runAbortable(comm->comm, comm->guard, comm->device, "ncclRecv of the rows", [&] {
+    runAbortable(comm->comm, comm->gate, comm->device, "ncclRecv of the rows", [&](ncclComm_t nc) {
       checkNccl(api->groupStart(), "ncclGroupStart");
       for (int r = 0; r < world; ++r) {
         if (r == root || rowsOf(r) == 0) continue;

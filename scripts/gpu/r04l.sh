@@ -1,4 +1,13 @@
 #!/bin/bash
+# RETIRED (round 6): this script drives the library through the PTW_SEQ_* / PTW_PIX_* / PTW_TEST_*
+# environment switches of rounds 2-4.  ABI v5 (commit 916a1dc is the last with them) replaced those by
+# ptw_debug_options (`--debug name=value` in the CLI and bench.py, Context.set_debug in Python): run against
+# HEAD it would time the DEFAULT dispatch under the old labels.  Kept as the record of how profiles/r04* were
+# taken; to re-run it, check out 916a1dc.
+if [ "${PTW_ALLOW_RETIRED_SCRIPT:-0}" != "1" ]; then
+  echo "$0: retired - needs commit 916a1dc (the PTW_SEQ_*/PTW_PIX_* environment switches are gone; use --debug)" >&2
+  exit 2
+fi
 # round 4: shares of the scene per worker wave by the wave's place - older / younger wave of a worker pair,
 # master-side wave (PTW_SEQ_UNITS="o,y,m"; profiles/r04k_*: the younger waves are the slow ones) - on ce
 # (rows [0, 8) of 2048 x 2048 @ 1024): parity of two settings against the oracle, then timing.

@@ -1,4 +1,13 @@
 #!/bin/bash
+# RETIRED (round 6): this script drives the library through the PTW_SEQ_* / PTW_PIX_* / PTW_TEST_*
+# environment switches of rounds 2-4.  ABI v5 (commit 916a1dc is the last with them) replaced those by
+# ptw_debug_options (`--debug name=value` in the CLI and bench.py, Context.set_debug in Python): run against
+# HEAD it would time the DEFAULT dispatch under the old labels.  Kept as the record of how profiles/r04* were
+# taken; to re-run it, check out 916a1dc.
+if [ "${PTW_ALLOW_RETIRED_SCRIPT:-0}" != "1" ]; then
+  echo "$0: retired - needs commit 916a1dc (the PTW_SEQ_*/PTW_PIX_* environment switches are gone; use --debug)" >&2
+  exit 2
+fi
 # Round 4 evidence run (one gpurun call) on the library AS SHIPPED: the whole GPU suite, the default
 # bench line, rocprofv3 --kernel-trace --stats of the same command, the PMC passes behind
 # profiles/hbm_traffic.json (sequential + the lock-step PERPIXEL kernel), BASELINE cfg3 / cfg4 under the

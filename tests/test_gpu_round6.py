@@ -1,0 +1,196 @@
+"""GPU: round-6 additions.
+
+* BASELINE cfg3 at its real frame: suzanne 1024 x 1024, passes {0, 1}, the kernel cfg3 runs
+  (`traceSequential<3,6,lds,stack,2 masters>`) - every sample's RNG word count and pick checksum, every
+  pixel's fp64 sum, against the oracle (until round 5 the driver-witnessed suzanne frames were 16 x 16 and
+  48 x 48; the whole-frame comparison existed only as a builder-side file);
+* BASELINE cfg4 at its real width: ce 2048 x [0, 64) x 2 passes under `<10,6,global,stack,2 masters>`, with
+  picks (under the SEQUENTIAL policy a prefix of the rows is exactly what the full pass produces for them);
+* a scene an OBJ user would bring: suzanne subdivided to 24 200 triangles with four MTL materials, through
+  `ptw_scene_load_obj_text`, under both RNG policies and the BVH mode - most of its triangles lie beyond the
+  resident slots of the worker waves, i.e. in the streamed tail (src/util/ObjLoaderImpl.h:55-103 loads
+  anything; src/dod/Scene.cpp:51-122 tests it all).
+
+The GPU render is asynchronous (ptw_context_render never waits), so the host computes the oracle's frame
+while the device traces: the two large cases cost about as long as the slower of the two sides.
+"""
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)))
+
+
+def _render_async_then_oracle(pkg, ob, scene, cam, params, threads, **debug):
+    """Enqueues the device render (word counts + pick checksums), computes the oracle's frame on the host
+    meanwhile, then waits.  Returns (device: rgb, cnt, words, picks, kernel), (oracle: rgb, cnt, words, picks)."""
+    import torch
+    ctx = pkg.Context(0)
+    ctx.set_scene(scene)
+    ctx.enable_stats(True)
+    h, w, spp = params.height, params.width, params.samples_per_pixel
+    rgb = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+    cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    words = torch.zeros((spp, h, w), dtype=torch.int32, device="cuda")
+    pk = torch.zeros((spp, h, w), dtype=torch.int32, device="cuda")
+    ctx.set_debug(pkg.debug_options(d_picks=pk.data_ptr(), **debug))
+    ctx.render(cam, params, rgb.data_ptr(), cnt.data_ptr(), words.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    ref = ob.oracle_render_picks(scene.view(), cam, params, threads=threads)
+    torch.cuda.synchronize()
+    kernel = ctx.stats(reset=True).trace_kernel.decode()
+    dev = (rgb.cpu().numpy(), cnt.cpu().numpy().astype(np.uint32), words.cpu().numpy().astype(np.uint32),
+           pk.cpu().numpy().astype(np.uint32), kernel)
+    return dev, ref
+
+
+def test_cfg3_whole_frame_two_passes(pkg, ob):
+    """suzanne 1024 x 1024 (BASELINE cfg3's frame), passes {0, 1}, the two-master kernel cfg3 dispatches to."""
+    w = h = 1024
+    scene = pkg.Scene()
+    cam = scene.build_named("suzanne", w, h)
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=2, seed=1)
+    (rgb, cnt, words, picks, kernel), (r_rgb, r_cnt, r_words, r_picks) = _render_async_then_oracle(
+        pkg, ob, scene, cam, params, threads=2, seq_two_masters=1)
+    assert kernel == "traceSequential<3,6,lds,stack,2 masters>", kernel
+    assert np.array_equal(cnt, r_cnt) and int(cnt.sum()) == 2 * w * h
+    assert int(np.count_nonzero(words != r_words)) == 0, "a path decision diverged somewhere in the frame"
+    assert int(np.count_nonzero(picks != r_picks)) == 0, "a ray hit another primitive than in the oracle"
+    assert rel_err(rgb, r_rgb) < TOL
+    assert np.all(rgb == r_rgb, axis=2).mean() > 0.999
+
+
+def test_cfg4_full_width_prefix(pkg, ob):
+    """ce 2048 wide (BASELINE cfg4's rows), rows [0, 64) x 2 passes under the kernel cfg4 runs."""
+    w = h = 2048
+    rows = 64
+    scene = pkg.Scene()
+    cam = scene.build_named("ce", w, h)
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=2, seed=1, row_begin=0, row_end=rows)
+    (rgb, cnt, words, picks, kernel), (r_rgb, r_cnt, r_words, r_picks) = _render_async_then_oracle(
+        pkg, ob, scene, cam, params, threads=2, seq_two_masters=1)
+    assert kernel == "traceSequential<10,6,global,stack,2 masters>", kernel
+    assert np.array_equal(cnt, r_cnt) and int(cnt.sum()) == 2 * w * rows and int(cnt[rows:].sum()) == 0
+    assert int(np.count_nonzero(words != r_words)) == 0
+    assert int(np.count_nonzero(picks != r_picks)) == 0
+    assert rel_err(rgb, r_rgb) < TOL
+    # (the ce camera sits inside an emitter of diffuse 0 - every sample is that emission)
+    assert np.allclose(rgb[:rows] / 2.0, (0.5675, 0.75, 0.7425), rtol=0, atol=1e-13)
+
+
+# ---- a large OBJ scene -------------------------------------------------------------------------------------
+
+BIG_MTL = """newmtl green
+  Kd 0.247 0.788 0.298
+  Ni 1.3
+newmtl shiny
+  Kd 0.8 0.7 0.2
+  Ni 1.5
+  Ns 70
+newmtl lamp
+  Ke 2.5 2.0 1.5
+  Kd 0 0 0
+newmtl mirror
+  Kd 0.9 0.9 0.9
+  Ka 0.3 0.3 0.3
+  illum 3
+"""
+
+
+def subdivided_suzanne_obj(n=5):
+    """scenes/suzanne.obj with every (fan-triangulated) face cut into n x n triangles on its barycentric
+    grid: 968 n^2 triangles as OBJ text - shared `v` lines, `f` lines with positive and negative indices,
+    four materials by face."""
+    verts, faces = [], []
+    for line in (ROOT / "scenes" / "suzanne.obj").read_text().splitlines():
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == "v":
+            verts.append([float(x) for x in t[1:4]])
+        elif t[0] == "f":
+            idx = [int(x.split("/")[0]) - 1 for x in t[1:]]
+            faces += [(idx[0], idx[i], idx[i + 1]) for i in range(1, len(idx) - 1)]
+    verts = np.asarray(verts)
+    out = ["mtllib big.mtl", "o BigSuzanne"]
+    names = ["green", "shiny", "green", "mirror", "green", "lamp", "green", "green"]
+    nv = 0
+    for fi, (a, b, c) in enumerate(faces):
+        A, B, C_ = verts[a], verts[b], verts[c]
+        grid = {}
+        for i in range(n + 1):
+            for j in range(n + 1 - i):
+                p = A + (B - A) * (i / n) + (C_ - A) * (j / n)
+                out.append("v %.9f %.9f %.9f" % tuple(p))
+                nv += 1
+                grid[(i, j)] = nv
+        out.append("usemtl " + names[fi % len(names)])
+        for i in range(n):
+            for j in range(n - i):
+                tri = (grid[(i, j)], grid[(i + 1, j)], grid[(i, j + 1)])
+                if (fi + i + j) % 2:   # (the loader's asIndex: negative = relative to the vertices so far)
+                    tri = tuple(t - nv - 1 for t in tri)
+                out.append("f %d %d %d" % tri)
+                if i + j < n - 1:
+                    out.append("f %d %d %d" % (grid[(i + 1, j)], grid[(i + 1, j + 1)], grid[(i, j + 1)]))
+    return "\n".join(out) + "\n", len(faces) * n * n
+
+
+@pytest.fixture(scope="module")
+def big_scene(pkg):
+    text, ntri = subdivided_suzanne_obj(5)
+    scene = pkg.Scene()
+    scene.load_obj_text(text, BIG_MTL)
+    # the rest of the reference's suzanne scene (src/main/main.cpp:94-104): lights and the backdrop
+    light = pkg.material("light", (4, 4, 4))
+    scene.add_sphere((0.5, 1, 3), 1.0, light)
+    scene.add_sphere((1, 1, 3), 1.0, light)
+    backdrop = pkg.material("diffuse", (0.20, 0.30, 0.36))
+    tl, tr, bl, br = (-5, -5, -1), (5, -5, -1), (-5, 5, -1), (5, 5, -1)
+    scene.add_triangle(tl, tr, bl, backdrop)
+    scene.add_triangle(tr, bl, br, backdrop)
+    assert scene.view().num_triangles == ntri + 2 == 24202
+    return scene
+
+
+def _big_camera(pkg, w, h):
+    return pkg.set_focus(pkg.look_at((1, -0.45, 4), (1, -0.6, 0.4), (0, 1, 0), w, h, 40.0), (1, -0.6, 0.4), 0.01)
+
+
+@pytest.mark.parametrize("mode", ["sequential", "sequential-two-masters", "perpixel-lockstep", "perpixel-persistent", "bvh"])
+def test_obj_scene_of_24k_triangles_matches_oracle(pkg, ob, big_scene, mode):
+    """24 202 triangles through the OBJ / MTL text loader, 8 x 8 x 3 spp.  SEQUENTIAL: the worker waves hold
+    12 x 7 x 64 = 5 376 (one master) or 11 x 6 x 64 = 4 224 (two masters) triangles in registers - the other
+    19-20 thousand are the streamed tail; radiance, every sample's RNG word count and pick checksum.  PERPIXEL
+    (both kernels) and the BVH mode: radiance and word counts against the oracle under the same policy."""
+    import test_gpu_round3 as r3
+    w = h = 8
+    cam = _big_camera(pkg, w, h)
+    if mode.startswith("sequential"):
+        params = pkg.default_params(width=w, height=h, samples_per_pixel=3, seed=1)
+        ref_rgb, ref_cnt, ref_words, ref_picks = ob.oracle_render_picks(big_scene.view(), cam, params, threads=3)
+        debug = dict(seq_two_masters=1) if mode.endswith("two-masters") else {}
+        rgb, cnt, words, kernel, _, picks = r3._render_with_stats(pkg, big_scene, cam, params, picks=True, **debug)
+        want = "traceSequential<11,6,global,stack,2 masters>" if debug else "traceSequential<12,7,global,stack>"
+        assert kernel == want, kernel
+        assert np.array_equal(picks, ref_picks), "a ray hit another primitive than in the oracle"
+        assert len(np.unique(ref_picks)) > 20   # (the picks do tell the triangles apart here)
+    else:
+        extra = {}
+        if mode == "bvh":
+            extra["accel"] = pkg.ACCEL_BVH
+        else:
+            extra["pix_kernel"] = pkg.PIX_KERNEL_LOCKSTEP if mode.endswith("lockstep") else pkg.PIX_KERNEL_PERSISTENT
+        params = pkg.default_params(width=w, height=h, samples_per_pixel=3, seed=1, rng_policy=pkg.RNG_PERPIXEL, **extra)
+        ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(big_scene.view(), cam, params, threads=3)
+        rgb, cnt, words, kernel, _ = r3._render_with_stats(pkg, big_scene, cam, params)
+        want = {"bvh": "tracePerPixelBvh", "perpixel-lockstep": "tracePerPixel", "perpixel-persistent": "tracePerPixelPersistent"}[mode]
+        assert kernel == want, kernel
+    assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words)
+    assert rel_err(rgb, ref_rgb) < TOL
