@@ -222,8 +222,9 @@ typedef struct ptw_debug_options {
   int32_t seq_two_masters;      /* worker-wave kernels (scenes beyond 128 triangles), two passes per
                                    workgroup: -1 the dispatcher's rule (more passes than CUs), 0 never,
                                    1 always                                                           */
-  int32_t seq_pairing;          /* experiments build only: 1 = the PAIRED form of the two-master kernels
-                                   (two sub-samples in flight per master; measured slower); else off  */
+  int32_t seq_pairing;          /* RETIRED (kept for the layout of ABI v5): 1 asked for round 5's paired form
+                                   of the two-master kernels, which left the tree in round 6 (LAB.md) -
+                                   PTW_ERR_UNSUPPORTED now; -1 / 0 = off                               */
   int32_t seq_lds_tables;       /* shading tables: -1 in LDS when they fit, 0 in global memory        */
   int32_t seq_small_kernel;     /* scenes of at most 64 triangles: -1 the dispatcher's rule, 0 the
                                    plain single-wave kernel (LDS tables, LDS stack), 1 the register
@@ -232,8 +233,8 @@ typedef struct ptw_debug_options {
                                    younger / master-side worker wave; {0, 0, 0} = the library's split */
   int32_t pix_samples_per_lane; /* lock-step PERPIXEL kernel's grid-stride depth; 0 = default (8)     */
   int32_t pix_waves_per_simd;   /* persistent PERPIXEL kernel: 0 = default (4), 2, 3 or 4             */
-  int32_t gang_groups;          /* experiments build only: CUs per pass of traceSequentialGang
-                                   (0 never; 2, 4, 8 when they fit the device)                        */
+  int32_t gang_groups;          /* RETIRED like seq_pairing: CUs per pass of round 3's traceSequentialGang;
+                                   > 0 is PTW_ERR_UNSUPPORTED now, 0 = off                            */
   int32_t fail_shard;           /* ptw_render_ex(num_devices > 1) failure injection, -1 = none:       */
   int32_t fail_collective;      /*   shard that fails its set-up / its collective call / reports      */
   int32_t silent_shard;         /*   success WITHOUT entering the collective (the watchdog ends it)   */

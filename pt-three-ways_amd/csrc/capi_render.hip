@@ -1,13 +1,10 @@
 // capi_render.hip — the device half of the C ABI declared in include/ptw.h: context, scene
 // upload, and the render entry points that replace dod::Scene::render
-// (src/dod/Scene.cpp:197-254).  Only HIP runtime calls here; the kernels are in
-// ptw_kernels.hip and the strict-fp64 host precompute in host/precompute.cpp.
+// (src/dod/Scene.cpp:197-254).  Only HIP runtime calls here; the kernels are in the kernel
+// files of this directory (ptw_kernels.h lists their launchers) and the strict-fp64 host precompute in
+// host/precompute.cpp.
 #include "capi_common.h"
 #include "ptw_kernels.h"
-
-#ifndef PTW_EXPERIMENTS
-#define PTW_EXPERIMENTS 0
-#endif
 
 #include "../host/bvh.h"
 #include "../host/precompute.h"
@@ -85,9 +82,6 @@ struct ptw_context {
   DeviceArray<uint32_t> mtState, mtPos;
   DeviceArray<double> stage;
   DeviceArray<unsigned long long> sampleQueue; // work counter of the persistent kernel
-  DeviceArray<unsigned long long> countHist; // traceSequentialWide: committed sub-samples by levels reached
-  DeviceArray<unsigned char> wideCands;      // the many-candidate kernels: the candidate set of the current band
-  DeviceArray<unsigned char> gangRecords;    // traceSequentialGang: result exchange between the CUs of a pass
   DeviceArray<unsigned long long> rays; // per-pass intersect() counters, accumulated
   uint64_t rayCarry = 0;                // counts folded in when `rays` had to grow
   // Host sources of the asynchronous uploads of a render; they live in the context because
@@ -124,11 +118,10 @@ struct ptw_context {
   ptw_context() { ptw_debug_defaults(&debug); }
   LaunchHints hints() const {
     LaunchHints h;
-    h.seqTwoMasters = debug.seq_two_masters, h.seqPairing = debug.seq_pairing;
+    h.seqTwoMasters = debug.seq_two_masters;
     h.seqLdsTables = debug.seq_lds_tables, h.seqSmallKernel = debug.seq_small_kernel;
     for (int i = 0; i < 3; ++i) h.seqUnits[i] = debug.seq_units[i];
     h.pixSamplesPerLane = debug.pix_samples_per_lane, h.pixWavesPerSimd = debug.pix_waves_per_simd;
-    h.gangGroups = debug.gang_groups;
     return h;
   }
   void activate() const { check(hipSetDevice(device), "hipSetDevice"); }
@@ -257,7 +250,7 @@ TraceParams makeTraceParams(const ptw_context &ctx, const ptw_camera &cam,
   return t;
 }
 
-// PERPIXEL policy: lock-step or persistent kernel (ptw_kernels.hip, launchTracePerPixel)?  Which
+// PERPIXEL policy: lock-step or persistent kernel (perpixel.hip, launchTracePerPixel)?  Which
 // one is faster depends on how uniformly long the scene's paths are, which no host-side number
 // says.  ptw_context_calibrate() times a trial of both - about two million samples each, image rows
 // spread over the whole frame, all passes' worth of lanes - and the context remembers the winner
@@ -379,22 +372,17 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   if (minBands > 1) bandPix = std::min<uint64_t>(bandPix, (pixTotal + minBands - 1) / minBands);
   bandPix = std::max<uint64_t>(bandPix, 64);
   bandPix = std::min<uint64_t>(bandPix, pixTotal);
-  // The many-candidate sequential kernel (traceSequentialGang, experiments build) picks its
-  // speculation candidates per band from the statistics of
-  // the band before: give it a short first band to measure on and at least eight bands, so that
-  // the set follows the image from top to bottom.
   const LaunchHints hints = ctx.hints();
+  // Kernels that left the tree (LAB.md: the paired two-master form, several CUs per pass): asking for one is
+  // an error, not a silent run of the default dispatch under the old label.
+  if (ctx.debug.seq_pairing == 1 || ctx.debug.gang_groups > 0)
+    throw DeviceError(PTW_ERR_UNSUPPORTED, "ptw_debug_options.seq_pairing / gang_groups: those experimental kernels were retired "
+                                           "in round 6 (LAB.md names the commit that holds them)");
   if (ctx.debug.d_picks && !sequential)
     throw DeviceError(PTW_ERR_UNSUPPORTED, "the pick checksum (ptw_debug_options.d_picks) needs PTW_RNG_SEQUENTIAL");
-  TraceParams shape = t; // (what the dispatcher looks at: scene size, depth, pass count)
-  bool adaptive = sequential && pixTotal >= 16384 && seqGangGroups(shape, hints) > 0;
-  if (adaptive && ctx.debug.d_picks)
-    throw DeviceError(PTW_ERR_UNSUPPORTED, "traceSequentialGang (experiments build) has no pick checksum");
-  if (adaptive) bandPix = std::min<uint64_t>(bandPix, (pixTotal + 7) / 8);
   // equal bands (the last one is not a sliver)
   const uint64_t nBands = (pixTotal + bandPix - 1) / bandPix;
   bandPix = (pixTotal + nBands - 1) / nBands;
-  const uint32_t calibrationPix = adaptive ? 256u : 0u;
   ctx.stage.reserve(static_cast<size_t>(npass) * bandPix * 3);
   if (npass > ctx.rays.capacity) {
     ctx.rayCarry += ctx.drainRays();
@@ -436,22 +424,9 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   ctx.sampleQueue.reserve(1);
   b.sampleQueue = ctx.sampleQueue.ptr;
   b.specState = sequential ? ctx.specState.ptr : nullptr;
-#if PTW_EXPERIMENTS
-  if (sequential && !ctx.countHist.ptr) {
-    ctx.countHist.reserve(8);
-    check(hipMemsetAsync(ctx.countHist.ptr, 0, 8 * sizeof(unsigned long long), stream), "memset");
-  }
-  if (sequential) {
-    ctx.wideCands.reserve(wideCandidateBytes());
-    ctx.gangRecords.reserve(gangRecordBytes(npass));
-  }
-#endif
   b.bvhNodes = ctx.bvhNodes.ptr;
   b.bvhLeafGeom = ctx.bvhLeafGeom.ptr;
   b.bvhLeafIndex = ctx.bvhLeafIndex.ptr;
-  b.countHist = ctx.countHist.ptr;     // (these three: the experiments build only, null otherwise)
-  b.wideCands = ctx.wideCands.ptr;
-  b.gangRecords = ctx.gangRecords.ptr;
 
   auto timedLaunch = [&](bool trace, auto &&launch) {
     if (!ctx.statsEnabled) {
@@ -478,7 +453,6 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   for (uint32_t begin = 0; begin < pixTotal;) {
     t.pixBegin = begin;
     t.pixCount = static_cast<uint32_t>(std::min<uint64_t>(bandPix, pixTotal - begin));
-    if (begin == 0 && calibrationPix) t.pixCount = std::min(t.pixCount, calibrationPix);
     begin += t.pixCount;
     t.firstBand = t.pixBegin == 0;
     const char *variant = "";

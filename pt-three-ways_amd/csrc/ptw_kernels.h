@@ -107,10 +107,7 @@ struct TraceBuffers {
   uint32_t *picks;           // optional [npass][npix]: per-sample pick checksum (SEQUENTIAL kernels)
   unsigned long long *rays;  // optional [npass] intersect() call counters
   unsigned long long *sampleQueue; // one word: next sample index (tracePerPixelPersistent)
-  double *specState;         // [npass][kSpecStateDoubles] parked stream ring (traceSequentialSpec / Wide)
-  unsigned long long *countHist; // [8]: committed sub-samples by levels reached (traceSequentialWide)
-  void *wideCands;               // wideCandidateBytes(): the candidate set of the many-candidate kernels
-  void *gangRecords;             // gangRecordBytes(npass): result exchange of traceSequentialGang (zeroed per launch)
+  double *specState;         // [npass][kSpecStateDoubles] parked stream ring (traceSequentialSpec)
   // accelerated mode (host/bvh.h)
   const void *bvhNodes;
   const double *bvhLeafGeom;
@@ -120,26 +117,15 @@ struct TraceBuffers {
 // What ptw_debug_options asks of the launchers (include/ptw.h; the defaults leave every decision to
 // the dispatch rules).  Tests and A/B runs only.
 struct LaunchHints {
-  int seqTwoMasters = -1, seqPairing = -1, seqLdsTables = -1, seqSmallKernel = -1;
+  int seqTwoMasters = -1, seqLdsTables = -1, seqSmallKernel = -1;
   int seqUnits[3] = {0, 0, 0};
-  int pixSamplesPerLane = 0, pixWavesPerSimd = 0, gangGroups = 0;
+  int pixSamplesPerLane = 0, pixWavesPerSimd = 0;
 };
 
 // SEQUENTIAL policy: one workgroup per pass walks the band's pixels in row-major order.
 // `variant` (may be null) receives the name of the kernel variant that was launched.
 hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints,
                                  hipStream_t stream, const char **variant = nullptr);
-// The candidate set of the many-candidate kernel (traceSequentialGang, experiments build): b.countHist
-// (zeroed once) and b.wideCands (wideCandidateBytes()) - before the trace kernel a one-lane kernel builds
-// the set from the histogram of per-sub-sample draw counts the previous launch left in countHist.
-size_t wideCandidateBytes();
-// traceSequentialGang (several CUs per pass, for renders with fewer passes than CUs): the number of
-// workgroups per pass the dispatcher will use for this launch shape on the current device (0: the
-// kernel does not apply), and the size of its exchange buffer.
-int seqGangGroups(const TraceParams &p, const LaunchHints &hints);
-size_t gangRecordBytes(uint32_t npass);
-// Builds the candidate set (n candidates) for the next launch from b.countHist into b.wideCands.
-hipError_t launchBuildCandidates(const TraceParams &p, const TraceBuffers &b, int n, hipStream_t stream);
 // PERPIXEL policy: one lane per (pass, pixel) sample.
 hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints,
                                hipStream_t stream, const char **variant = nullptr);

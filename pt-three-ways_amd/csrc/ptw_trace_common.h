@@ -1,5 +1,5 @@
-// ptw_trace_common.h — device code shared by the radiance kernels of ptw_kernels.hip (and of
-// csrc/experiments/): nearest-hit primitives (Scene::intersect*, src/dod/Scene.cpp:13-113), the camera
+// ptw_trace_common.h — device code shared by the radiance kernels of csrc/ (ptw_launch.h lists the kernel
+// files): nearest-hit primitives (Scene::intersect*, src/dod/Scene.cpp:13-113), the camera
 // ray (src/math/Camera.h:20-60) and the std::mt19937 stream ring of the speculative kernels.
 #pragma once
 
@@ -206,18 +206,6 @@ __device__ __noinline__ void specGenerateBlock(uint32_t *x, char *ring, unsigned
 
 // Commands of the tracing waves to the generator wave (one word per barrier parity).
 constexpr uint32_t kGenNone = 0, kGenSlot0 = 1, kGenSlot1 = 2, kGenExit = 3;
-
-
-// The candidate set of the many-candidate speculative kernels (device memory, written per band by
-// wideBuildCandidates, experiments/ptw_gang.h, from the measured histogram of per-sub-sample draw counts).
-constexpr int kWideMaxCand = 64;
-struct WideCandidates {
-  uint16_t node[kWideMaxCand]; // candidate c = m << 8 | D: sub-sample j + m, D draws after the frontier
-  uint32_t succ[kWideMaxCand]; // 6-bit fields: the candidate that continues c when c consumed 3 (k + 1)
-                               // draws, k = 0..4 (63: not in the set)
-  int32_t count;
-  int32_t maxD; // largest D in the list (how far ahead of the frontier a round reads)
-};
 
 } // namespace
 } // namespace ptw

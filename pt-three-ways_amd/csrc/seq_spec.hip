@@ -1,0 +1,459 @@
+// seq_spec.hip - traceSequentialSpec: the SEQUENTIAL policy for scenes of at most 64 triangles with the
+// first-bounce fan-out traced speculatively by four waves (the headline kernel).
+#include "ptw_launch.h"
+#include "ptw_seq_ctx.h"
+
+namespace ptw {
+using namespace ptwd;
+namespace {
+
+// -----------------------------------------------------------------------------------------
+// traceSequentialSpec: SEQUENTIAL policy for scenes of at most 64 triangles, with the
+// sub-samples of the first-bounce fan-out traced SPECULATIVELY in parallel.
+//
+// The stream makes everything serial: sub-sample j+1 starts where sub-sample j stopped, and how
+// many draws j consumes (3 per level it reaches) is known only when it is done.  But that count
+// takes few values, and the values repeat (a closed scene mostly runs every path to the depth cap,
+// an open one mostly loses the first ray).  So a workgroup of kSpecWaves waves - one per SIMD of
+// a CU, each holding the whole scene in registers like the single-wave kernel - works per round
+// on:  wave 0: sub-sample j at the true stream position (the frontier);
+//      wave 1: sub-sample j+1, assuming j consumes m1 (the most recent count);
+//      wave 2: sub-sample j+1 assuming m2 (the most recent different count) - or, while no second
+//              value has been seen, sub-sample j+3 assuming m1 three times;
+//      wave 3: sub-sample j+2, assuming m1 twice.
+// After a barrier every wave reads all results and commits, in order, as many sub-samples as the
+// assumptions allow (always j; j+1 if a wave started where j really stopped; and so on).  Wrong
+// guesses cost nothing but the energy: the result is the one the serial order defines, bit for bit
+// - each wave accumulates the committed contributions itself, in sub-sample order.
+//
+// For that the stream must be readable ahead of the frontier: the generator output sits in a
+// ring of two blocks (SeqCtx SPEC mode); while the frontier is in one block the next one is
+// already there, and when the frontier crosses into it, wave 0 generates the block after it into
+// the slot that just became free.
+// -----------------------------------------------------------------------------------------
+constexpr int kSpecWaves = 4;
+
+struct alignas(16) SpecResult { // one per wave and round parity, in LDS
+  double L[3]; // radiance of the sub-path below the first-bounce surface
+  int meta;    // canonical doubles consumed | lobe at the first-bounce surface << 8 | rays << 16
+  int pad;
+};
+
+__host__ __device__ inline size_t specLdsBytes(uint32_t ntri, uint32_t nmat, uint32_t nsph) {
+  size_t n = 2 * kRingStride;                          // the ring
+  n += kMtWords * sizeof(uint32_t);                    // raw generator state
+  n += 2 * kSpecWaves * sizeof(SpecResult);            // results, double-buffered
+  n += 64 + kSeqCamBytes;                              // generator commands, the camera
+  n = (n + 63) & ~static_cast<size_t>(63);
+  n += static_cast<size_t>(nsph) * sizeof(SphereRec);
+  n += static_cast<size_t>(ntri) * kTriCompactDoubles * sizeof(double);
+  n += static_cast<size_t>(nmat) * kMatDoubles * sizeof(double);
+  // more than half of a CU's 160 KB: one workgroup per CU, so its four waves get a SIMD each
+  const size_t floor = 84 * 1024;
+  return n < floor ? floor : n;
+}
+
+template <bool PICKS>
+__global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
+    const TraceParams p, const double *__restrict__ triGeom, const SphereRec *__restrict__ spheres,
+    const double *__restrict__ triCompact, const double *__restrict__ matTable,
+    uint32_t *__restrict__ mtState, double *__restrict__ specState, double *__restrict__ stage,
+    uint32_t *__restrict__ words, unsigned long long *__restrict__ rayCounters, uint32_t *__restrict__ picks) {
+  extern __shared__ __attribute__((aligned(64))) unsigned char ldsRaw[];
+  constexpr int kBlock = 64 * (kSpecWaves + 1);
+  char *ring = reinterpret_cast<char *>(ldsRaw);
+  uint32_t *mt = reinterpret_cast<uint32_t *>(ldsRaw + 2 * kRingStride);
+  SpecResult *results = reinterpret_cast<SpecResult *>(mt + kMtWords);
+  // (taken from ldsRaw inside the lambdas too: a captured pointer loses its LDS address space and
+  // the stores turn into flat instructions with a vmcnt wait)
+  constexpr size_t kGenCmdOffset = 2 * kRingStride + kMtWords * sizeof(uint32_t) + 2 * kSpecWaves * sizeof(SpecResult);
+  uint32_t *genCmd = reinterpret_cast<uint32_t *>(ldsRaw + kGenCmdOffset);
+  size_t off = 2 * kRingStride + kMtWords * sizeof(uint32_t) + 2 * kSpecWaves * sizeof(SpecResult) + 64;
+  // (the camera in LDS: as part of the kernel argument its 36 dwords were spilled to vector-register lanes
+  // and read back for every pixel - see kSeqCamBytes)
+  ptw_camera *camLds = reinterpret_cast<ptw_camera *>(ldsRaw + off);
+  off += kSeqCamBytes;
+  off = (off + 63) & ~static_cast<size_t>(63);
+  if (threadIdx.x < sizeof(ptw_camera) / sizeof(double))
+    reinterpret_cast<double *>(camLds)[threadIdx.x] = reinterpret_cast<const double *>(&p.cam)[threadIdx.x];
+
+  const int pass = blockIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+
+  using Ctx = SeqCtx<1, 1, true, true, true, 1, PICKS>;
+  Ctx ctx;
+  ctx.triCompactGlobal = triCompact;
+  ctx.matTableGlobal = matTable;
+  ctx.p = &p;
+  ctx.envColour = ld3(p.env);
+  asm volatile("" : "+v"(ctx.envColour.x), "+v"(ctx.envColour.y), "+v"(ctx.envColour.z));
+  ctx.triGeom = triGeom;
+  ctx.spheresGlobal = spheres;
+  ctx.sh = nullptr;
+  ctx.tid = lane; // every wave owns the whole scene: lane k holds triangle k
+  ctx.stack = nullptr;
+  ctx.partials = nullptr;
+  ctx.cmd = nullptr;
+  ctx.words = 0;
+  ctx.rays = 0;
+  ctx.parity = 0;
+  ctx.picksOn = PICKS && picks != nullptr;
+  ctx.pickReset();
+  ctx.ringBase = ring;
+  {
+    SphereRec *ls = reinterpret_cast<SphereRec *>(ldsRaw + off);
+    double *lt = reinterpret_cast<double *>(ls + p.nsph);
+    double *lm = lt + static_cast<size_t>(p.ntri) * kTriCompactDoubles;
+    const double *gs = reinterpret_cast<const double *>(spheres);
+    double *lsd = reinterpret_cast<double *>(ls);
+    for (uint32_t i = threadIdx.x; i < p.nsph * (sizeof(SphereRec) / 8); i += kBlock) lsd[i] = gs[i];
+    for (uint32_t i = threadIdx.x; i < p.ntri * kTriCompactDoubles; i += kBlock) lt[i] = triCompact[i];
+    for (uint32_t i = threadIdx.x; i < p.nmat * kMatDoubles; i += kBlock) lm[i] = matTable[i];
+    ctx.tab.sph = ls;
+    ctx.tab.tri = lt;
+    ctx.tab.mat = lm;
+  }
+  const bool isGenerator = wave == kSpecWaves; // the fifth wave only produces the stream
+  if (!isGenerator) ctx.loadPrimitives();
+
+  // ---- the stream: resume (or start) this pass's generator ring ----
+  uint32_t *myState = mtState + static_cast<size_t>(pass) * kMtWords;
+  double *myPark = specState + static_cast<size_t>(pass) * kSpecStateDoubles;
+  for (int i = threadIdx.x; i < kMtWords; i += kBlock) mt[i] = myState[i];
+  unsigned fOff = 0; // frontier: ring slot (0 or kRingStride) ...
+  int fQ = 0;        // ... and position in it
+  if (p.firstBand) {
+    __syncthreads();
+    if (isGenerator) {
+      specGenerateBlock(mt, ring, 0, lane);           // block 0
+      specGenerateBlock(mt, ring, kRingStride, lane); // block 1 (completes block 0's overlap)
+    }
+  } else {
+    for (int i = threadIdx.x; i < 2 * kRingCanonDoubles; i += kBlock) {
+      const int slot = i / kRingCanonDoubles, k = i - slot * kRingCanonDoubles;
+      reinterpret_cast<double *>(ring + slot * kRingStride)[k] = myPark[i];
+    }
+    fOff = __builtin_amdgcn_readfirstlane(static_cast<int>(myPark[2 * kRingCanonDoubles])) ? kRingStride : 0u;
+    fQ = __builtin_amdgcn_readfirstlane(static_cast<int>(myPark[2 * kRingCanonDoubles + 1]));
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * kMtDoubles; i += kBlock) {
+      const int slot = i / kMtDoubles, q = i - slot * kMtDoubles;
+      const double *cn = reinterpret_cast<const double *>(ring + slot * kRingStride);
+      hemiEntry(cn[q], cn[q + 1], reinterpret_cast<double *>(ring + slot * kRingStride + kRingHemiOff) + 3 * q);
+    }
+  }
+  __syncthreads();
+
+  // ---- the generator wave: serves one command per workgroup barrier until told to exit ----
+  if (isGenerator) {
+    for (unsigned k = 0;; ++k) {
+      ldsBarrier();
+      const uint32_t cmd = genCmd[k & 1];
+      if (cmd == kGenExit) break;
+      if (cmd == kGenSlot0) specGenerateBlock(mt, ring, 0, lane);
+      if (cmd == kGenSlot1) specGenerateBlock(mt, ring, kRingStride, lane);
+    }
+  } else {
+  // Stream bookkeeping of the tracing waves (identical in all of them).  When the frontier
+  // enters the other slot, the slot it left is handed to the generator wave with the next
+  // barrier (genState 1 -> 2); the block is complete once the barrier after that has been passed
+  // (2 -> 0), because the generator arrives there only when it is done.  The tracing waves
+  // read at most `ahead` draws beyond the frontier, so they only have to wait for an
+  // outstanding block when the frontier comes that close to the end of its slot.
+  unsigned barriers = 0;
+  int genState = 0;
+  unsigned genSlot = 0;
+  const int ahead = 12 * (p.maxDepth > 0 ? p.maxDepth : 1) + 8;
+  auto roundBarrier = [&](uint32_t exitCmd) {
+    if (threadIdx.x == 0)
+      reinterpret_cast<uint32_t *>(ldsRaw + kGenCmdOffset)[barriers & 1] =
+          exitCmd ? exitCmd : (genState == 1 ? (genSlot ? kGenSlot1 : kGenSlot0) : kGenNone);
+    ldsBarrier();
+    ++barriers;
+    genState = genState == 1 ? 2 : 0;
+  };
+  auto ensureAhead = [&]() {
+    while (genState != 0 && fQ + ahead >= kMtDoubles) roundBarrier(0);
+  };
+  auto advanceFrontier = [&](int n) { // n < kMtDoubles
+    const int np = fQ + n;
+    if (np >= kMtDoubles) {
+      genSlot = fOff; // the slot left behind takes the block after the next
+      genState = 1;
+      fQ = np - kMtDoubles;
+      fOff ^= kRingStride;
+    } else {
+      fQ = np;
+    }
+  };
+
+  const int w = p.width;
+  const bool lens = uniformBool(camLds->aperture_radius != 0);
+  const int nSub = p.fbU * p.fbV;
+  const int vShift = p.fbV > 0 ? 31 - __builtin_clz(static_cast<unsigned>(p.fbV)) : 0;
+  // Per-round constants in vector registers: as kernel arguments they sit in a 16-register
+  // scalar tuple that does not survive the rounds and would be re-read from its spill lanes
+  // (eighteen v_readlane) for every sub-sample.
+  double invU = p.invU, invV = p.invV;
+  asm volatile("" : "+v"(invU), "+v"(invV));
+  const bool fastFan = (p.uPow2 & p.vPow2) != 0;
+  const int vMask = p.fbV - 1;
+  double *myStage = stage + static_cast<size_t>(pass) * p.pixCount * 3;
+  unsigned long long raysTotal = 0;
+  // The guesses: m1 = the most frequent count of draws a sub-sample has consumed so far in this
+  // pass (3 per level reached), m2 = the second most frequent (m2 == m1 while only one value has
+  // been seen).  `hist` counts them in 6-bit fields, halved when a field passes 31.
+  int m1 = 3 * (p.maxDepth > 0 ? p.maxDepth : 1), m2 = m1;
+  unsigned long long hist = 0;
+  int parity = 0;
+#if PTW_PROFILE_PHASES
+  unsigned long long stRounds = 0, stCommits = 0, stWork = 0, stWait = 0, stCommit = 0, stPrimary = 0;
+  unsigned long long stOk1 = 0, stOk2a = 0, stOk3 = 0, stOk2b = 0, stIdle = 0;
+  const unsigned long long stT0 = __builtin_amdgcn_s_memtime();
+#endif
+
+  for (uint32_t i = 0; i < p.pixCount; ++i) {
+    const uint32_t pix = p.pixBegin + i;
+    const int px = static_cast<int>(pix % static_cast<uint32_t>(w));
+    const int py = static_cast<int>(pix / static_cast<uint32_t>(w));
+    // ---- every wave: camera ray and first hit at the frontier (redundant, in parallel) ----
+    PTW_T(tP0);
+    ensureAhead();
+    ctx.setStream(fOff, fQ);
+    double r0, r1, r2 = 0, r3 = 0;
+    if (lens) {
+      ctx.draw4(r0, r1, r2, r3);
+    } else {
+      r0 = ctx.draw();
+      r1 = ctx.draw();
+    }
+    const int camDraws = lens ? 4 : 2;
+    d3 o, d;
+    cameraRay(*camLds, px, py, r0, r1, r2, r3, o, d);
+    int sampleDraws = camDraws;
+    ctx.pickReset();
+    uint32_t pickSum = 0, pickBase = 1; // the sample's pick checksum; intersect() calls committed so far
+    d3 L = mk(0, 0, 0);
+    bool traced = false;
+    HitKey k0;
+    k0.t = kInf, k0.idx = kMiss, k0.det = 0;
+    if (p.maxDepth > 0) {
+      k0 = ctx.intersect(o, d);
+      raysTotal++;
+      if (PICKS) pickSum = ctx.pickS2; // (the primary ray is call 0)
+      if (uniformBool(k0.idx == kMiss)) {
+        L = ld3(p.env);
+      } else {
+        traced = true;
+      }
+    }
+    advanceFrontier(camDraws);
+#if PTW_PROFILE_PHASES
+    stPrimary += __builtin_amdgcn_s_memtime() - tP0;
+#endif
+    if (traced) {
+      const Surface first = ctx.surfaceAt(k0, o, d);
+      if (p.preview) {
+        L = first.diffuse; // Scene.cpp:137-138
+      } else {
+        d3 result = mk(0, 0, 0);
+        int j = 0;
+        if (hist != 0) { // refresh the guesses once per sample
+          if (hist & 0x0820820820820820ull) hist = (hist >> 1) & 0x07df7df7df7df7dfull;
+          int best = 0, bestN = -1, second = 0, secondN = 0;
+#pragma unroll
+          for (int f = 1; f <= 9; ++f) {
+            const int n = static_cast<int>(hist >> (6 * f)) & 63;
+            const bool top = n > bestN;
+            const bool sec = !top & (n > secondN);
+            second = top ? best : (sec ? f : second);
+            secondN = top ? bestN : (sec ? n : secondN);
+            best = top ? f : best;
+            bestN = top ? n : bestN;
+          }
+          m1 = 3 * best;
+          m2 = secondN > 0 ? 3 * second : m1;
+        }
+        while (j < nSub) {
+          ensureAhead();
+          // ---- this wave's assignment: sub-sample j + ioff, stream position frontier + delta ----
+          const bool oneMode = m2 == m1;
+          int ioff = 0, delta = 0;
+          if (wave == 1) ioff = 1, delta = m1;
+          if (wave == 2) ioff = oneMode ? 3 : 1, delta = oneMode ? 3 * m1 : m2;
+          if (wave == 3) ioff = 2, delta = 2 * m1;
+          const int myIdx = j + ioff;
+          PTW_T(tW0);
+          SpecResult mine;
+          mine.L[0] = mine.L[1] = mine.L[2] = 0;
+          mine.meta = 0, mine.pad = 0;
+          if (myIdx < nSub) {
+            const int np = fQ + delta; // delta < kMtDoubles
+            const bool wrap = np >= kMtDoubles;
+            ctx.setStream(wrap ? fOff ^ kRingStride : fOff, wrap ? np - kMtDoubles : np);
+            ctx.words = 0;
+            ctx.rays = 0;
+            ctx.pickReset();
+            // sub-sample index -> stratum (uS, vS) -> stratified (u, v); ONE decision for the
+            // usual power-of-two fan-outs (shift / mask / multiply), the general case apart
+            double xu, xv, pd;
+            ctx.draw3(xu, xv, pd);
+            double u, v;
+            if (fastFan) {
+              const int uS = myIdx >> vShift, vS = myIdx & vMask;
+              u = (static_cast<double>(uS) + xu) * invU;
+              v = (static_cast<double>(vS) + xv) * invV;
+            } else {
+              const int uS = myIdx / p.fbV, vS = myIdx - uS * p.fbV;
+              const double ur = static_cast<double>(uS) + xu, vr = static_cast<double>(vS) + xv;
+              u = p.uPow2 ? ur * invU : ur / static_cast<double>(p.fbU);
+              v = p.vPow2 ? vr * invV : vr / static_cast<double>(p.fbV);
+            }
+            d3 nd;
+            const bool refl = scatter(ctx, first, d, u, v, pd, nd);
+            const d3 child = ctx.chainHot(p, first.pos, nd);
+            mine.L[0] = child.x, mine.L[1] = child.y, mine.L[2] = child.z;
+            mine.meta = static_cast<int>(ctx.words >> 1) | (refl ? 0x100 : 0) |
+                        (static_cast<int>(ctx.rays) << 16);
+            if (PICKS) mine.pad = static_cast<int>(ctx.pickS1 | (ctx.pickS2 << 16)); // (<= 9 calls of <= 127 primitives)
+          }
+          SpecResult *slot = results + parity * kSpecWaves;
+          if (lane == 0) slot[wave] = mine;
+          PTW_T(tW1);
+          roundBarrier(0);
+          PTW_T(tW2);
+          // ---- commit (the scalar part identical in every wave) ----
+          const int metaV = slot[lane & 3].meta;
+          const int meta0 = __builtin_amdgcn_readlane(metaV, 0), meta1 = __builtin_amdgcn_readlane(metaV, 1);
+          const int meta2 = __builtin_amdgcn_readlane(metaV, 2), meta3 = __builtin_amdgcn_readlane(metaV, 3);
+          const int c0 = meta0 & 0xff, c1 = meta1 & 0xff, c2 = meta2 & 0xff, c3 = meta3 & 0xff;
+          // The assignments this round was made with, and which of them held - as all-ones /
+          // zero integer masks in scalar registers (conditions kept as C++ bools become lane masks
+          // that take a trip through a vector register per use).
+          auto eq = [](int a, int b) { return ((a ^ b) - 1) >> 31; };  // a, b >= 0: -1 if equal
+          auto lt = [](int a, int b) { return (a - b) >> 31; };        // -1 if a < b
+          const int d1 = m1, d2 = oneMode ? 3 * m1 : m2, d3v = 2 * m1;
+          const int w2Second = oneMode ? 0 : -1; // wave 2 ran sub-sample j+1 (else j+3)
+          const int ok1 = lt(j + 1, nSub) & eq(d1, c0);
+          const int ok2a = lt(j + 1, nSub) & ~ok1 & w2Second & eq(d2, c0);
+          const int cur1 = c0 + (c1 & ok1) + (c2 & ok2a);
+          const int two = ok1 | ok2a;
+          const int ok3 = two & lt(j + 2, nSub) & eq(d3v, cur1);
+          const int cur2 = cur1 + (c3 & ok3);
+          const int ok2b = ok3 & lt(j + 3, nSub) & ~w2Second & eq(d2, cur2);
+          const int cur = cur2 + (c2 & ok2b);
+          const int nIdx = 1 - two - ok3 - ok2b;
+          // histogram of the committed counts (6-bit fields indexed by count / 3)
+          auto note = [&](int on, int c) {
+            hist += (1ull << (6 * ((c * 11) >> 5))) & static_cast<unsigned long long>(static_cast<long long>(on));
+          };
+          note(-1, c0);
+          note(ok1, c1);
+          note(ok2a, c2);
+          note(ok3, c3);
+          note(ok2b, c2);
+          raysTotal += static_cast<unsigned>(meta0 >> 16) + (static_cast<unsigned>(meta1 >> 16) & ok1) +
+                       (static_cast<unsigned>(meta2 >> 16) & (ok2a | ok2b)) +
+                       (static_cast<unsigned>(meta3 >> 16) & ok3);
+          if (PICKS && picks && wave == 0) { // the committed sub-samples' picks, in sub-sample order
+            auto addPicks = [&](int wv, int meta) {
+              const uint32_t pw = static_cast<uint32_t>(slot[wv].pad);
+              pickSum += pickBase * (pw & 0xffffu) + (pw >> 16);
+              pickBase += static_cast<uint32_t>(meta) >> 16;
+            };
+            addPicks(0, meta0);
+            if (ok1) addPicks(1, meta1);
+            if (ok2a) addPicks(2, meta2);
+            if (ok3) addPicks(3, meta3);
+            if (ok2b) addPicks(2, meta2);
+          }
+          if (wave == 0) { // only the wave that stores the sample needs the radiance
+            auto add = [&](int wv, int meta) {
+              const SpecResult &r = slot[wv];
+              const d3 child = mk(r.L[0], r.L[1], r.L[2]);
+              result = result + ((meta & 0x100) ? first.emission + child
+                                                : first.emission + first.diffuse * child);
+            };
+            add(0, meta0);
+            if (ok1) add(1, meta1);
+            if (ok2a) add(2, meta2);
+            if (ok3) add(3, meta3);
+            if (ok2b) add(2, meta2);
+          }
+          j += nIdx;
+          sampleDraws += cur;
+          parity ^= 1;
+          advanceFrontier(cur);
+#if PTW_PROFILE_PHASES
+          stRounds++, stCommits += nIdx;
+          stOk1 -= ok1, stOk2a -= ok2a, stOk3 -= ok3, stOk2b -= ok2b, stIdle += !(myIdx < nSub);
+          stWork += tW1 - tW0, stWait += tW2 - tW1, stCommit += __builtin_amdgcn_s_memtime() - tW2;
+#endif
+        }
+        L = result * p.invFirstBounce;
+      }
+    }
+    if (threadIdx.x == 0) {
+      myStage[i * 3 + 0] = L.x;
+      myStage[i * 3 + 1] = L.y;
+      myStage[i * 3 + 2] = L.z;
+      if (words) words[static_cast<size_t>(pass) * p.npix + pix] = 2u * static_cast<unsigned>(sampleDraws);
+      if (PICKS && picks) picks[static_cast<size_t>(pass) * p.npix + pix] = pickSum;
+    }
+  }
+
+  while (genState != 0) roundBarrier(0); // an outstanding block must be in the ring that gets parked
+  roundBarrier(kGenExit);
+#if PTW_PROFILE_PHASES
+  if (pass == 0 && lane == 0) {
+    const double n = static_cast<double>(p.pixCount);
+    printf("SPEC wave %d: cycles/sample=%.0f rounds/sample=%.2f commits/round=%.2f primary=%.0f work=%.0f "
+           "wait=%.0f commit+advance=%.0f (per sample)\n",
+           wave, (__builtin_amdgcn_s_memtime() - stT0) / n, stRounds / n,
+           static_cast<double>(stCommits) / stRounds, stPrimary / n, stWork / n, stWait / n, stCommit / n);
+    printf("SPEC wave %d: per round ok1=%.3f ok2a=%.3f ok3=%.3f ok2b=%.3f idle=%.3f\n", wave,
+           (double)stOk1 / stRounds, (double)stOk2a / stRounds, (double)stOk3 / stRounds,
+           (double)stOk2b / stRounds, (double)stIdle / stRounds);
+  }
+#endif
+  if (threadIdx.x == 0) {
+    myPark[2 * kRingCanonDoubles] = fOff ? 1.0 : 0.0;
+    myPark[2 * kRingCanonDoubles + 1] = static_cast<double>(fQ);
+    if (rayCounters) rayCounters[pass] += raysTotal;
+  }
+  } // tracing waves
+  // ---- park the stream for the next band ----
+  __syncthreads();
+  for (int i = threadIdx.x; i < kMtWords; i += kBlock) myState[i] = mt[i];
+  for (int i = threadIdx.x; i < 2 * kRingCanonDoubles; i += kBlock) {
+    const int slot = i / kRingCanonDoubles, k = i - slot * kRingCanonDoubles;
+    myPark[i] = reinterpret_cast<const double *>(ring + slot * kRingStride)[k];
+  }
+}
+
+} // namespace
+
+// the scenes the register-resident kernels handle (the REG variant of the single-wave kernel, traceSequentialSpec)
+bool specApplies(const TraceParams &p) {
+  return p.ntri <= 64 && p.nsph <= 64 && p.nsph + p.ntri <= 127 && p.maxDepth <= 9 &&
+         seqLdsBytes(1, p.maxDepth, true, p.ntri, p.nmat, p.nsph) <= kLdsTableBudget;
+}
+
+hipError_t launchSeqSpec(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
+  setVariant("traceSequentialSpec");
+  const size_t lds = specLdsBytes(p.ntri, p.nmat, p.nsph);
+  auto kernel = b.picks ? traceSequentialSpec<true> : traceSequentialSpec<false>;
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kernel, dim3(p.npass), dim3(64 * (kSpecWaves + 1)), lds, stream, p,
+                     b.triGeom, b.spheres, b.triCompact, b.matTable, b.mtState, b.specState, b.stage,
+                     b.words, b.rays, b.picks);
+  return hipGetLastError();
+}
+
+} // namespace ptw

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Register / spill metadata of every kernel in a device-only assembly file
-(hipcc --offload-arch=gfx950 -O3 -Icsrc --cuda-device-only -S csrc/ptw_kernels.hip -o k.s):
+(hipcc --offload-arch=gfx950 -O3 -Icsrc --cuda-device-only -S csrc/seq_spec.hip -o k.s; any kernel file of csrc/):
     python scripts/isa_meta.py k.s [filter]"""
 import re
 import subprocess

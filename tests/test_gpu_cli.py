@@ -10,19 +10,11 @@ pytestmark = pytest.mark.gpu
 
 def run_cli(pkg, args, cwd, env=None, debug=None):
     """`debug`: ptw_debug_options fields for the CLI's --debug flag (dispatch forced for the test);
-    `env`: PTW_STAGE_BUDGET_KB (the one knob the library reads from the environment here) and
-    PTW_USE_EXPERIMENTS (this helper's own: run against the experiments build)."""
+    `env`: PTW_STAGE_BUDGET_KB (the one knob the library reads from the environment here)."""
     import os
     exe = pkg.LIB_PATH.parent / "pt_three_ways_hip"
     if debug:
         args = ["--debug", ",".join(f"{k}={v}" for k, v in debug.items())] + list(args)
-    if env and env.get("PTW_USE_EXPERIMENTS"):
-        # the experiments build (make experiments) has the same soname in its own directory; the CLI
-        # finds the shipped library through RUNPATH=$ORIGIN, which LD_LIBRARY_PATH precedes
-        exp_dir = pkg.LIB_PATH.parent / "experiments"
-        if not (exp_dir / "libptw_hip.so").exists():
-            pytest.skip("experiments library not built (make -C pt-three-ways_amd experiments)")
-        env = dict(env, LD_LIBRARY_PATH=str(exp_dir) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
     proc = subprocess.run([str(exe)] + args, cwd=cwd, capture_output=True, text=True, timeout=300,
                           env=dict(os.environ, **env) if env else None)
     assert proc.returncode == 0, proc.stdout + proc.stderr
@@ -74,19 +66,13 @@ def test_chunked_save_every_and_png_and_merge(pkg, tmp_path):
 def test_sequential_kernel_variants_write_identical_bytes(pkg, tmp_path, scene, extra):
     """The speculative four-wave kernel, the single-wave register-stack kernel and the plain
     single-wave kernel are schedules of one computation: same .raw bytes.  A tiny staging budget makes
-    every pass park and resume its stream dozens of times.  The opt-in kernel of the experiments
-    build (several CUs per pass) is held to the same bytes when that build is present."""
+    every pass park and resume its stream dozens of times."""
     from conftest import ROOT
     args = ["-w", "40", "-h", "28", "--spp", "5", "--seed", "11", "--scene", scene, "--raw", "--save-every", "0"] + extra
     # name -> (environment, --debug fields)
     variants = {"spec": ({}, {}), "reg": ({}, {"seq_small_kernel": 1}), "plain": ({}, {"seq_small_kernel": 0}),
                 "spec_bands": ({"PTW_STAGE_BUDGET_KB": "12"}, {}),
                 }
-    exp = {"PTW_USE_EXPERIMENTS": "1"}
-    if (pkg.LIB_PATH.parent / "experiments" / "libptw_hip.so").exists() and not extra:
-        variants.update({
-            "gang8": (exp, {"gang_groups": 8}), "gang4_bands": (dict(exp, PTW_STAGE_BUDGET_KB="12"), {"gang_groups": 4}),
-            "gang2": (exp, {"gang_groups": 2})})
     blobs = {}
     for name, (env, debug) in variants.items():
         run_cli(pkg, args + [str(tmp_path / f"{name}.raw")], ROOT, env=env, debug=debug)
@@ -100,18 +86,13 @@ def test_two_master_worker_kernel_writes_identical_bytes(pkg, tmp_path, scene, s
     """Scenes beyond 128 triangles: the kernel with two passes (two master waves) per workgroup over
     six shared worker waves against the one-master kernel: same .raw bytes, for even and odd pass
     counts (an odd count leaves the last workgroup one master without a pass) and when every pass
-    parks and resumes its generator between bands; the paired form of the experiments build (two
-    sub-samples in flight per master: measured slower) is held to the same bytes."""
+    parks and resumes its generator between bands."""
     from conftest import ROOT
     args = ["-w", "24", "-h", "18", "--spp", str(spp), "--seed", "4", "--scene", scene, "--raw", "--save-every", "0"]
     bands = {"PTW_STAGE_BUDGET_KB": "8"}
     variants = {"one": ({}, {"seq_two_masters": 0}),
                 "two": ({}, {"seq_two_masters": 1}),
                 "two_bands": (bands, {"seq_two_masters": 1})}
-    if (pkg.LIB_PATH.parent / "experiments" / "libptw_hip.so").exists():
-        exp = {"PTW_USE_EXPERIMENTS": "1"}
-        variants["two_paired"] = (exp, {"seq_two_masters": 1, "seq_pairing": 1})
-        variants["two_paired_bands"] = (dict(exp, **bands), {"seq_two_masters": 1, "seq_pairing": 1})
     blobs = {}
     for name, (env, debug) in variants.items():
         run_cli(pkg, args + [str(tmp_path / f"{name}.raw")], ROOT, env=env, debug=debug)

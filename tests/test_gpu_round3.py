@@ -68,7 +68,7 @@ def _render_with_stats(pkg, scene, cam, params, picks=False, **debug):
     return out + (pk.cpu().numpy().astype(np.uint32),) if picks else out
 
 
-# (triangles, shading tables, the instantiation that must run) - ptw_kernels.hip dispatchSequential
+# (triangles, shading tables, the instantiation that must run) - dispatch.hip dispatchSequential, seq_worker2.hip
 TWO_MASTER_CASES = [
     (200, "lds", "traceSequential<1,6,lds,stack,2 masters"),
     (200, "global", "traceSequential<1,6,global,stack,2 masters"),
@@ -86,10 +86,9 @@ TWO_MASTER_CASES = [
 ]
 
 
-def two_master_case(pkg, ob, ntri, tables, kernel, spp, budget_kb, pairing=0):
-    """One case of test_two_master_kernels_match_oracle (also run by tests/test_gpu_round5.py against the
-    experiments build, with pairing = 1).  PTW_STAGE_BUDGET_KB must be set by the caller."""
-    debug = dict(seq_two_masters=1, seq_pairing=pairing)
+def two_master_case(pkg, ob, ntri, tables, kernel, spp, budget_kb):
+    """One case of test_two_master_kernels_match_oracle.  PTW_STAGE_BUDGET_KB must be set by the caller."""
+    debug = dict(seq_two_masters=1)
     if tables == "global" and ntri < 1400:
         debug["seq_lds_tables"] = 0
     w, h = (12, 10) if budget_kb else (4, 3)   # (a band is at least 64 pixels)
@@ -97,7 +96,7 @@ def two_master_case(pkg, ob, ntri, tables, kernel, spp, budget_kb, pairing=0):
     params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=5)
     ref_rgb, ref_cnt, ref_words, ref_picks = ob.oracle_render_picks(scene.view(), cam, params, threads=4)
     rgb, cnt, words, variant, launches, picks = _render_with_stats(pkg, scene, cam, params, picks=True, **debug)
-    assert variant == kernel + (",paired>" if pairing else ">"), variant
+    assert variant == kernel + ">", variant
     if budget_kb:
         assert launches > 1, "the staging budget did not cut the frame into bands"
     assert np.array_equal(cnt, ref_cnt)
@@ -137,7 +136,7 @@ def test_two_master_natural_dispatch_more_passes_than_cus(pkg, ob, ntri, nsph, k
 
 @pytest.mark.parametrize("name,edge,spp,kernel", [("suzanne", 16, 6, "traceSequential<3,6,lds,stack,2 masters"),
                                                   ("ce", 6, 5, "traceSequential<10,6,global,stack,2 masters")])
-def test_two_master_kernels_on_the_baseline_scenes(pkg, ob, name, edge, spp, kernel, pairing=0):
+def test_two_master_kernels_on_the_baseline_scenes(pkg, ob, name, edge, spp, kernel):
     """suzanne and ce - the scenes of cfg3 / cfg4 - directly against the oracle under the two-master
     kernels they run there.  On ce neither the radiance nor the RNG word counts can depend on which
     primitive a ray hits (every primary ray ends on an emitter of diffuse 0, every ray hits something):
@@ -146,15 +145,14 @@ def test_two_master_kernels_on_the_baseline_scenes(pkg, ob, name, edge, spp, ker
     cam = scene.build_named(name, edge, edge)
     params = pkg.default_params(width=edge, height=edge, samples_per_pixel=spp, seed=1)
     ref_rgb, ref_cnt, ref_words, ref_picks = ob.oracle_render_picks(scene.view(), cam, params, threads=6)
-    rgb, cnt, words, variant, _, picks = _render_with_stats(pkg, scene, cam, params, picks=True, seq_two_masters=1,
-                                                            seq_pairing=pairing)
-    assert variant == kernel + (",paired>" if pairing else ">"), variant
+    rgb, cnt, words, variant, _, picks = _render_with_stats(pkg, scene, cam, params, picks=True, seq_two_masters=1)
+    assert variant == kernel + ">", variant
     assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words)
     assert np.array_equal(picks, ref_picks), "a ray hit another primitive than in the oracle"
     assert rel_err(rgb, ref_rgb) < TOL
 
 
-def test_a_dropped_unit_of_triangles_shows_in_the_pick_checksum(pkg, ob, pairing=0):
+def test_a_dropped_unit_of_triangles_shows_in_the_pick_checksum(pkg, ob):
     """The negative control of the comparisons above ("a worker wave that lost a unit
     of triangles would still pass - and run faster").  On ce ITSELF no output can show that: none of its
     rays ever hits a triangle (tests/test_oracle_picks.py: the frame with and without the mesh is the
@@ -168,19 +166,19 @@ def test_a_dropped_unit_of_triangles_shows_in_the_pick_checksum(pkg, ob, pairing
     cam = scene.build_named("ce", 6, 6)
     params = pkg.default_params(width=6, height=6, samples_per_pixel=4, seed=1)
     ref_rgb, _, ref_words, ref_picks = ob.oracle_render_picks(scene.view(), cam, params, threads=4)
-    full = _render_with_stats(pkg, scene, cam, params, picks=True, seq_two_masters=1, seq_pairing=pairing, seq_units=(9, 7, 9))
+    full = _render_with_stats(pkg, scene, cam, params, picks=True, seq_two_masters=1, seq_units=(9, 7, 9))
     assert full[3].startswith("traceSequential<9,6,global,stack,2 masters"), full[3]
     assert np.array_equal(full[2], ref_words) and np.array_equal(full[5], ref_picks) and rel_err(full[0], ref_rgb) < TOL
     # (b)
     soup, scam = _soup(pkg, 3300, 2, seed=99, w=6, h=4)
     sparams = pkg.default_params(width=6, height=4, samples_per_pixel=3, seed=8)
     _, _, swords, spicks = ob.oracle_render_picks(soup.view(), scam, sparams, threads=4)
-    good = _render_with_stats(pkg, soup, scam, sparams, picks=True, seq_two_masters=1, seq_pairing=pairing)
+    good = _render_with_stats(pkg, soup, scam, sparams, picks=True, seq_two_masters=1)
     assert good[3].startswith("traceSequential<10,6,global,stack,2 masters"), good[3]
     assert np.array_equal(good[2], swords) and np.array_equal(good[5], spicks)
     unit = pick_helpers.find_sensitive_unit(pkg, ob, soup, scam, sparams)
     bad = _render_with_stats(pkg, pick_helpers.scene_without_unit(pkg, soup, unit), scam, sparams, picks=True,
-                             seq_two_masters=1, seq_pairing=pairing)
+                             seq_two_masters=1)
     assert not np.array_equal(bad[5], spicks), "the pick checksum did not notice 64 missing triangles"
 
 
@@ -519,17 +517,8 @@ def test_calibration_trial_fits_a_tiny_staging_buffer(pkg, monkeypatch):
     assert np.array_equal(rgb_small, rgb_full) and np.array_equal(cnt_small, cnt_full)
 
 
-# ---- several CUs per pass (traceSequentialGang; experiments build only) ---------------------------
-GANG_SCRIPT = r"""
-import os, sys
-sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
-import numpy as np
-import torch
-import oracle_binding as ob
-pkg = ob.pkg
-TOL = 1e-12
-
-def small_soup(ntri, nsph, shell, seed, w, h):
+# ---- the small-scene kernels on the cases round 3's several-CUs-per-pass kernel was held to ---------------
+def _small_soup(pkg, ntri, nsph, shell, seed, w, h):
     rng = np.random.default_rng(seed)
     scene = pkg.Scene()
     mats = [pkg.material("diffuse", rng.uniform(0.2, 0.9, 3)), pkg.material("light", rng.uniform(0.5, 3.0, 3)),
@@ -548,66 +537,42 @@ def small_soup(ntri, nsph, shell, seed, w, h):
     cam = pkg.set_focus(pkg.look_at((0, 0.5, 7), (0, 0, 0), (0, 1, 0), w, h, 45.0), (0, 0, 0), 0.02)
     return scene, cam
 
-CASES = [
-    dict(scene="cornell", w=40, h=28, spp=5, over={{}}),
+
+SMALL_SCENE_CASES = [
+    dict(scene="cornell", w=40, h=28, spp=5, over={}),
     dict(scene="cornell", w=24, h=16, spp=9, over=dict(first_bounce_u=3, first_bounce_v=5), budget_kb=12),
     dict(scene="single-sphere", w=24, h=16, spp=3, over=dict(max_depth=3)),
     dict(soup=(33, 20, False), w=24, h=16, spp=4, over=dict(max_depth=8, first_bounce_u=2, first_bounce_v=2), budget_kb=12),
     dict(soup=(64, 62, True), w=24, h=16, spp=2, over=dict(max_depth=4, first_bounce_u=1, first_bounce_v=7)),
     dict(soup=(1, 0, True), w=16, h=12, spp=8, over=dict(max_depth=9)),
 ]
-for groups in (2, 4, 8):
-    for case in CASES:
-        os.environ.pop("PTW_STAGE_BUDGET_KB", None)
+
+
+@pytest.mark.parametrize("kernel,debug", [("traceSequentialSpec", {}), ("traceSequential<1,1,lds,reg>", dict(seq_small_kernel=1)),
+                                          ("traceSequential<1,1,lds,stack>", dict(seq_small_kernel=0))])
+def test_small_scene_kernels_match_oracle(pkg, ob, monkeypatch, kernel, debug):
+    """The three kernels for scenes of at most 64 triangles - four speculating waves per pass, one wave with
+    its (E, T) stack in scalar registers, one wave with the stack in LDS - against the oracle with pick
+    checksums: closed and open scenes, every depth, odd fan-outs (the speculative kernel's general stratum
+    path), primitive counts at the kernels' limits (64 triangles + 62 spheres + a shell = 127 primitives),
+    streams parked and resumed between bands.  (These are the cases round 3's several-CUs-per-pass kernel was
+    held to; that kernel left the tree in round 6, LAB.md.)"""
+    for n, case in enumerate(SMALL_SCENE_CASES):
+        monkeypatch.delenv("PTW_STAGE_BUDGET_KB", raising=False)
         if case.get("budget_kb"):
-            os.environ["PTW_STAGE_BUDGET_KB"] = str(case["budget_kb"])
+            monkeypatch.setenv("PTW_STAGE_BUDGET_KB", str(case["budget_kb"]))
         w, h = case["w"], case["h"]
         if "scene" in case:
-            scene = pkg.Scene(); cam = scene.build_named(case["scene"], w, h)
+            scene = pkg.Scene()
+            cam = scene.build_named(case["scene"], w, h)
         else:
-            scene, cam = small_soup(*case["soup"], seed=4321 + groups, w=w, h=h)
+            scene, cam = _small_soup(pkg, *case["soup"], seed=4321 + n, w=w, h=h)
         params = pkg.default_params(width=w, height=h, samples_per_pixel=case["spp"], seed=77, **case["over"])
-        ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(scene.view(), cam, params, threads=4)
-        ctx = pkg.Context(0); ctx.set_scene(scene); ctx.enable_stats(True); ctx.set_debug(gang_groups=groups)
-        rgb = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
-        cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
-        words = torch.zeros((case["spp"], h, w), dtype=torch.int32, device="cuda")
-        ctx.render(cam, params, rgb.data_ptr(), cnt.data_ptr(), words.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
-        st = ctx.stats(reset=True)
-        assert st.trace_kernel.decode() == f"traceSequentialGang<{{groups}} CUs per pass>", st.trace_kernel
-        assert not case.get("budget_kb") or st.trace_launches > 1
-        got = rgb.cpu().numpy()
-        assert not np.isnan(got).any(), "a workgroup gave up waiting for its peers"
-        assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), ref_cnt)
-        assert np.array_equal(words.cpu().numpy().astype(np.uint32), ref_words), "a path decision diverged"
-        assert float(np.max(np.abs(got - ref_rgb) / np.maximum(np.abs(ref_rgb), 1.0))) < TOL
-# more passes than fit the device with 8 CUs each: the one-CU kernel runs instead
-cus = torch.cuda.get_device_properties(0).multi_processor_count
-scene = pkg.Scene(); cam = scene.build_named("cornell", 8, 6)
-params = pkg.default_params(width=8, height=6, samples_per_pixel=cus // 8 + 1, seed=1)
-ctx = pkg.Context(0); ctx.set_scene(scene); ctx.enable_stats(True); ctx.set_debug(gang_groups=8)
-rgb = torch.zeros((6, 8, 3), dtype=torch.float64, device="cuda"); cnt = torch.zeros((6, 8), dtype=torch.int32, device="cuda")
-ctx.render(cam, params, rgb.data_ptr(), cnt.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
-torch.cuda.synchronize()
-assert ctx.stats(reset=True).trace_kernel.decode() == "traceSequentialSpec"
-print("GANG_OK")
-"""
-
-
-def test_gang_kernel_matches_oracle(pkg, tmp_path):
-    """traceSequentialGang (experiments build: 2, 4 or 8 CUs per pass, their 8 / 16 / 32 speculative
-    candidates meeting through global memory once per round) against the oracle: sums to 1e-12, every
-    sample's RNG word count exact; closed and open scenes, every depth, odd fan-outs, streams parked
-    and resumed between bands; and the fallback when the workgroups would not all be resident.  The
-    kernel is not in the shipped library (it measured no faster than one CU per pass on the headline
-    scene), so the comparison runs in a child process on experiments/libptw_hip.so."""
-    from conftest import ROOT
-    lib = pkg.LIB_PATH.parent / "experiments" / "libptw_hip.so"
-    if not lib.exists():
-        pytest.skip("experiments library not built (make -C pt-three-ways_amd experiments)")
-    script = tmp_path / "gang.py"
-    script.write_text(GANG_SCRIPT.format(root=str(ROOT)))
-    proc = subprocess.run(["python", str(script)], env=dict(os.environ, PTW_LIB_PATH=str(lib)), capture_output=True,
-                          text=True, timeout=600)
-    assert proc.returncode == 0 and "GANG_OK" in proc.stdout, proc.stdout[-3000:] + proc.stderr[-3000:]
+        ref_rgb, ref_cnt, ref_words, ref_picks = ob.oracle_render_picks(scene.view(), cam, params, threads=4)
+        rgb, cnt, words, variant, launches, picks = _render_with_stats(pkg, scene, cam, params, picks=True, **debug)
+        assert variant == kernel, (variant, case)
+        assert not case.get("budget_kb") or launches > 1
+        assert np.array_equal(cnt, ref_cnt)
+        assert np.array_equal(words, ref_words), ("a path decision diverged", case)
+        assert np.array_equal(picks, ref_picks), ("a ray hit another primitive than in the oracle", case)
+        assert rel_err(rgb, ref_rgb) < TOL

@@ -238,7 +238,7 @@ def test_rccl_peer_that_exits_is_an_error_not_a_hang(tmp_path):
 @pytest.mark.parametrize("nbase", [140, 1100])
 @pytest.mark.parametrize("masters", [1, 0])
 @pytest.mark.parametrize("spp", [3, 4])
-def test_worker_wave_kernels_resolve_exact_ties_like_the_reference(pkg, ob, masters, spp, nbase, pairing=0):
+def test_worker_wave_kernels_resolve_exact_ties_like_the_reference(pkg, ob, masters, spp, nbase):
     """Scene::intersect scans the primitives in insertion order with a strict `<` (Scene.cpp:31,95,118):
     of several primitives hit at EXACTLY the same distance the one inserted first wins - and its
     material decides the path.  A scene of 140 large triangles, each with a copy 20 indices later (the
@@ -249,8 +249,7 @@ def test_worker_wave_kernels_resolve_exact_ties_like_the_reference(pkg, ob, mast
     lanes that hold it) and the two-candidates shortcut all meet exact ties on most rays.  1100 base
     triangles make 3300: the <10,6,global,2 masters> instantiation BASELINE cfg4 runs.  Against the
     oracle: fp64 sums to 1e-12, every sample's RNG word count and every sample's pick checksum (WHICH of
-    the tied primitives won), two masters and one (tests/test_gpu_round5.py: the paired form of the
-    experiments build)."""
+    the tied primitives won), two masters and one."""
     rng = np.random.default_rng(11)
     scene = pkg.Scene()
     mats = [pkg.material("diffuse", (0.9, 0.2, 0.2)), pkg.material("light", (2.5, 2.0, 1.5)),
@@ -272,12 +271,10 @@ def test_worker_wave_kernels_resolve_exact_ties_like_the_reference(pkg, ob, mast
     params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=21)
     ref_rgb, ref_cnt, ref_words, ref_picks = ob.oracle_render_picks(scene.view(), cam, params, threads=4)
     import test_gpu_round3 as r3
-    rgb, cnt, words, variant, _, picks = r3._render_with_stats(pkg, scene, cam, params, picks=True, seq_two_masters=masters,
-                                                               seq_pairing=pairing)
+    rgb, cnt, words, variant, _, picks = r3._render_with_stats(pkg, scene, cam, params, picks=True, seq_two_masters=masters)
     small = nbase == 140
-    want = {(1, 1): "traceSequential<2,6,lds,stack,2 masters,paired>" if small else "traceSequential<10,6,global,stack,2 masters,paired>",
-            (1, 0): "traceSequential<2,6,lds,stack,2 masters>" if small else "traceSequential<10,6,global,stack,2 masters>",
-            (0, 0): "traceSequential<1,7,lds,stack>" if small else "traceSequential<8,7,global,stack>"}[(masters, pairing)]
+    want = {1: "traceSequential<2,6,lds,stack,2 masters>" if small else "traceSequential<10,6,global,stack,2 masters>",
+            0: "traceSequential<1,7,lds,stack>" if small else "traceSequential<8,7,global,stack>"}[masters]
     assert variant == want, variant
     assert np.array_equal(cnt, ref_cnt)
     assert np.array_equal(words, ref_words), "a tie was resolved differently from the reference"

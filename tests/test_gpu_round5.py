@@ -1,10 +1,8 @@
 """GPU: round-5 additions.
 
-* the PAIRED form of the two-master worker-wave kernels (csrc/experiments/ptw_pair.h: two sub-samples of the
-  first-bounce fan-out in flight per master, two rays per request to the workers) - built in round 5,
-  measured slower than round 4's lock step, so it lives in the experiments build and is
-  held to the oracle there, in a child process: every instantiation, the BASELINE scenes, exact ties, the
-  natural dispatch - radiance sums, every sample's RNG word count and pick checksum;
+* the PAIRED form of the two-master worker-wave kernels (round 5: built four ways, bit-identical, slower -
+  LAB.md) was held to the oracle here through round 5 in the experiments build; it left the tree in round 6 and
+  what is tested now is that asking for it is an error;
 * BASELINE cfg1's exact shape (cornell 256 x 256 @ 8 spp, seed 1) through the C ABI and through the CLI;
 * the tile-shardable policy at the frame the metric is quoted on: both PERPIXEL kernels, the whole 1024 x 1024
   frame, against the oracle.
@@ -20,53 +18,29 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
-PAIRED_SCRIPT = r"""
-import os, sys
-sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
-import numpy as np
-import torch
-import oracle_binding as ob
-import test_gpu_round3 as r3
-import test_gpu_round4 as r4
-pkg = ob.pkg
-ran = set()
-for ntri, tables, kernel in r3.TWO_MASTER_CASES:
-    for spp, budget_kb in ((3, None), (4, 1)):
-        os.environ.pop("PTW_STAGE_BUDGET_KB", None)
-        if budget_kb:
-            os.environ["PTW_STAGE_BUDGET_KB"] = str(budget_kb)
-        r3.two_master_case(pkg, ob, ntri, tables, kernel, spp, budget_kb, pairing=1)
-        ran.add(kernel)
-os.environ.pop("PTW_STAGE_BUDGET_KB", None)
-for name, edge, spp, kernel in (("suzanne", 16, 6, "traceSequential<3,6,lds,stack,2 masters"),
-                                ("ce", 6, 5, "traceSequential<10,6,global,stack,2 masters")):
-    r3.test_two_master_kernels_on_the_baseline_scenes(pkg, ob, name, edge, spp, kernel, pairing=1)
-r3.test_a_dropped_unit_of_triangles_shows_in_the_pick_checksum(pkg, ob, pairing=1)
-for nbase in (140, 1100):
-    for spp in (3, 4):
-        r4.test_worker_wave_kernels_resolve_exact_ties_like_the_reference(pkg, ob, 1, spp, nbase, pairing=1)
-# odd fan-outs, other depths, a pinhole camera (two camera draws), an open scene
-for over in (dict(first_bounce_u=3, first_bounce_v=5), dict(max_depth=2), dict(max_depth=9, first_bounce_u=2, first_bounce_v=1),
-             dict(max_depth=3, first_bounce_u=1, first_bounce_v=2)):
-    scene, cam = r3._soup(pkg, 700, 3, seed=17, w=8, h=8)
-    params = pkg.default_params(width=8, height=8, samples_per_pixel=4, seed=3, **over)
-    ref_rgb, ref_cnt, ref_words, ref_picks = ob.oracle_render_picks(scene.view(), cam, params, threads=4)
-    rgb, cnt, words, variant, _, picks = r3._render_with_stats(pkg, scene, cam, params, picks=True, seq_two_masters=1, seq_pairing=1)
-    assert variant.endswith(",2 masters,paired>"), variant
-    assert np.array_equal(words, ref_words) and np.array_equal(picks, ref_picks) and r3.rel_err(rgb, ref_rgb) < 1e-12, over
-print("PAIRED_OK", len(ran))
-"""
 
-
-def test_paired_two_master_kernels_match_oracle_in_the_experiments_build(pkg, tmp_path):
-    lib = pkg.LIB_PATH.parent / "experiments" / "libptw_hip.so"
-    if not lib.exists():
-        pytest.skip("experiments library not built (make -C pt-three-ways_amd experiments)")
-    script = tmp_path / "paired.py"
-    script.write_text(PAIRED_SCRIPT.format(root=str(ROOT)))
-    proc = subprocess.run([sys.executable, str(script)], env=dict(os.environ, PTW_LIB_PATH=str(lib)),
-                          capture_output=True, text=True, timeout=900)
-    assert proc.returncode == 0 and "PAIRED_OK 12" in proc.stdout, proc.stdout[-1500:] + proc.stderr[-3000:]
+def test_retired_experimental_kernels_are_refused(pkg):
+    """ptw_debug_options.seq_pairing / gang_groups selected the two experimental kernels of rounds 3 and 5 (the
+    paired form of the two-master kernels, several CUs per pass).  Both were measured slower and left the tree
+    in round 6 (LAB.md); ABI v5 keeps the fields, and asking for either kernel is an error - not a silent run of
+    the default dispatch under the old label."""
+    import torch
+    scene = pkg.Scene()
+    cam = scene.build_named("cornell", 8, 8)
+    params = pkg.default_params(width=8, height=8, samples_per_pixel=2, seed=1)
+    rgb = torch.zeros((8, 8, 3), dtype=torch.float64, device="cuda")
+    cnt = torch.zeros((8, 8), dtype=torch.int32, device="cuda")
+    for debug in (dict(seq_pairing=1), dict(gang_groups=4)):
+        ctx = pkg.Context(0)
+        ctx.set_scene(scene)
+        ctx.set_debug(**debug)
+        with pytest.raises(pkg.PtwError) as err:
+            ctx.render(cam, params, rgb.data_ptr(), cnt.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        assert err.value.status == 8 and "retired" in str(err.value), err.value   # 8 = PTW_ERR_UNSUPPORTED
+        ctx.set_debug()           # the defaults render
+        ctx.render(cam, params, rgb.data_ptr(), cnt.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    assert int(cnt.sum().item()) == 2 * 2 * 64
 
 
 def test_baseline_cfg1_shape(pkg, ob, tmp_path):

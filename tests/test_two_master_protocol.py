@@ -1,12 +1,9 @@
-"""CPU models of the barrier protocols of the two-master worker kernel
-(pt-three-ways_amd/csrc/ptw_kernels.hip: SeqCtx<..., MASTERS = 2>::intersect / workerLoop /
-stopWorkers and the role set-up in traceSequential): the LOCK STEP the shipped kernels run (round 2's;
-first half of this file), and the PAIRED form of the experiments build (csrc/experiments/ptw_pair.h,
-round 5: one barrier per tick, the two command slots of BOTH masters searched alternately as one
-two-ray request - second half).  (Round 4's decoupled protocol - request and answer numbers in LDS, no
-barrier - left the tree in round 5 with its model; last revision 916a1dc.)
-
-Lock step:
+"""CPU model of the barrier protocol of the two-master worker kernel
+(pt-three-ways_amd/csrc/ptw_seq_ctx.h: SeqCtx<..., MASTERS = 2>::intersect / workerLoop / stopWorkers, and
+the role set-up in traceSequential, ptw_seq_kernel.h): the LOCK STEP the shipped kernels run.  (Round 4's
+decoupled protocol - request and answer numbers in LDS, no barrier - left the tree in round 5 with its model,
+last revision 916a1dc; round 5's paired form - one barrier per tick, two-ray requests - in round 6, last
+revision 89c2934; LAB.md.)
 
 Every wave of the workgroup is a generator that yields at each workgroup barrier; the scheduler
 releases a barrier only when ALL live waves have arrived (what s_barrier does), so a protocol in
@@ -138,7 +135,7 @@ def test_lock_step_protocol_all_ray_counts():
 
 
 def worker_rank(wave, masters, workers):
-    """traceSequential's `workerRank` (ptw_kernels.hip): `tid` order of the worker waves - the waves
+    """traceSequential's `workerRank` (ptw_seq_kernel.h): `tid` order of the worker waves - the waves
     that share a SIMD with a master (waves go to the four SIMDs round robin: wave 4 sits with wave 0,
     wave 5 with wave 1) come last."""
     r = wave - masters
@@ -180,134 +177,3 @@ def test_slot_major_assignment_gives_the_empty_slots_to_the_waves_beside_a_maste
             # the waves beside a master never hold more than any other wave
             load = {w: sum(1 for hw, _ in holder.values() if hw == w) for w in ranks}
             assert max(load[w] for w in shared) <= min(load[w] for w in ranks if w not in shared)
-
-
-# ---- the paired form (experiments build): one barrier per tick, command slots alternate -------------
-class PairGroup:
-    def __init__(self):
-        self.op = [LIVE, LIVE]                      # SeqCommand::op
-        self.mask = [0, 0]                          # SeqCommand::nrays: bit c = slot c holds a ray
-        self.ray = [[None, None], [None, None]]     # [master][slot]
-        self.answers = [[[None] * WORKERS for _ in range(2)] for _ in range(2)]   # [master][slot][worker]
-        self.searched = []                          # (barrier, master, slot, ray id), logged by worker 0
-        self.reads = []                             # (master, slot, ray id, answers)
-
-
-def pair_master(g, m, chains, has_pass):
-    """pairRun(): after barrier b the master works on slot c = (b + 1) & 1 - takes the answers of the ray
-    it put there two barriers ago, puts the next ray of that slot's chain in place (or leaves the slot
-    empty), updates bit c of its mask - while slot b & 1 of both masters is searched.  `chains`: per slot
-    the number of rays its chain traces in this pass (the model's stand-in for the path logic)."""
-    if not has_pass:
-        g.op[m] = 0
-        n = 0
-    else:
-        left = list(chains)
-        inflight = [None, None]
-        serial = 0
-        if left[0] > 0:                             # before barrier 0: the first ray, slot 0
-            g.ray[m][0] = inflight[0] = (m, 0, serial)
-            serial += 1
-            left[0] -= 1
-            g.mask[m] = 1
-        b = 0
-        more = inflight[0] is not None or left[1] > 0
-        if not more:
-            g.op[m] = 0
-        while more:
-            yield "B"                               # barrier b
-            c = (b + 1) & 1
-            if inflight[c] is not None and b > 0:
-                g.reads.append((m, c, inflight[c], list(g.answers[m][c])))
-                inflight[c] = None
-            bit = 0
-            if left[c] > 0:
-                g.ray[m][c] = inflight[c] = (m, c, serial)
-                serial += 1
-                left[c] -= 1
-                bit = 1
-            g.mask[m] = (g.mask[m] & ~(1 << c)) | (bit << c)
-            more = any(x is not None for x in inflight) or any(x > 0 for x in left)
-            if not more:
-                g.op[m] = b + 1                     # no rays from this master as of the next barrier
-            b += 1
-        n = b
-    while True:                                     # keep the cadence until the other one is done too
-        yield "B"
-        if g.op[0] <= n and g.op[1] <= n:
-            return
-        n += 1
-
-
-def pair_worker(g, w):
-    """workerLoopPair(): barrier n is followed by the search of slot n & 1 of both masters."""
-    n = 0
-    while True:
-        yield "B"
-        if g.op[0] <= n and g.op[1] <= n:
-            return
-        c = n & 1
-        for m in (0, 1):
-            if g.op[m] > n and (g.mask[m] >> c) & 1:
-                g.answers[m][c][w] = (g.ray[m][c], w)
-                if w == 0:
-                    g.searched.append((n, m, c, g.ray[m][c]))
-        n += 1
-
-
-def run_pair(chains0, chains1, has1=True, order_seed=None):
-    rnd = random.Random(order_seed) if order_seed is not None else None
-    g = PairGroup()
-    waves = [pair_master(g, 0, chains0, True), pair_master(g, 1, chains1, has1)] + [pair_worker(g, w) for w in range(WORKERS)]
-    live = list(range(len(waves)))
-    barriers = 0
-    left_at = {}
-    for _ in range(20 * (sum(chains0) + sum(chains1)) + 40):
-        arrived, done = [], []
-        if rnd:
-            rnd.shuffle(live)
-        for i in live:
-            try:
-                next(waves[i])
-                arrived.append(i)
-            except StopIteration:
-                done.append(i)
-        for i in done:
-            left_at[i] = barriers
-        live = arrived
-        if not live:
-            break
-        assert not done or not live, f"waves {done} left at barrier {barriers} while {live} still wait"
-        barriers += 1
-    assert not live, "deadlock"
-    assert len(set(left_at.values())) == 1
-    return g, barriers
-
-
-def test_paired_protocol_all_chain_lengths():
-    """Every ray a master puts into a slot is searched exactly once - by every worker, in the tick after
-    the barrier that follows it, together with the other master's ray of the same slot - and read back
-    with all six answers two barriers after it was placed; nobody deadlocks, everybody leaves after the
-    same barrier, whatever the two slots' chain lengths (an empty second slot, an empty pass, a master
-    without a pass) and whatever order the waves run in between barriers."""
-    lengths = [(a, b) for a in range(0, 5) for b in range(0, 4)]
-    for chains0, chains1, has1 in itertools.product(lengths, lengths, (True, False)):
-        if not has1 and sum(chains1):
-            continue
-        g, barriers = run_pair(chains0, chains1, has1)
-        placed0 = sum(chains0) if chains0[0] > 0 or chains0[1] > 0 else 0
-        placed1 = (sum(chains1) if has1 else 0)
-        assert len([1 for _, m, _, _ in g.searched if m == 0]) == placed0
-        assert len([1 for _, m, _, _ in g.searched if m == 1]) == placed1
-        assert len(set(ray for _, _, _, ray in g.searched)) == len(g.searched)          # each exactly once
-        assert sorted(ray for _, _, ray, _ in g.reads) == sorted(ray for _, _, _, ray in g.searched)
-        for m, c, ray, answers in g.reads:
-            assert answers == [(ray, w) for w in range(WORKERS)]
-        for n, m, c, ray in g.searched:
-            assert n & 1 == c                                                             # slots alternate
-        # one ray per slot and two barriers: the longer slot of the longer pass sets the length
-        longest = max(2 * max(chains0[0] - 0, 0), 2 * chains0[1] + 1, 2 * chains1[0] if has1 else 0, (2 * chains1[1] + 1) if has1 else 0)
-        assert barriers <= longest + 4
-        for seed in range(4):
-            g2, b2 = run_pair(chains0, chains1, has1, order_seed=seed)
-            assert b2 == barriers and sorted(g2.searched) == sorted(g.searched) and sorted(g2.reads) == sorted(g.reads)
