@@ -228,7 +228,9 @@ typedef struct ptw_debug_options {
   int32_t seq_lds_tables;       /* shading tables: -1 in LDS when they fit, 0 in global memory        */
   int32_t seq_small_kernel;     /* scenes of at most 64 triangles: -1 the dispatcher's rule, 0 the
                                    plain single-wave kernel (LDS tables, LDS stack), 1 the register
-                                   variant, 2 the speculative four-wave kernel whatever the pass count */
+                                   variant, 2 the speculative four-wave kernel whatever the pass count,
+                                   3 that kernel in its round-5 form (no camera ray of the next pixel
+                                   traced ahead in a pixel's last round) - the A/B switch of round 6     */
   int32_t seq_units[3];         /* worker-wave kernels: resident units of 64 triangles of an older /
                                    younger / master-side worker wave; {0, 0, 0} = the library's split */
   int32_t pix_samples_per_lane; /* lock-step PERPIXEL kernel's grid-stride depth; 0 = default (8)     */

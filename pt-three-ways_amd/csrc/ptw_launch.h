@@ -30,7 +30,7 @@ int deviceCus();
 // ---- SEQUENTIAL families (each defined in the file named above) --------------------------------------------
 // the scenes the register-resident kernels handle (REG variant of the single-wave kernel, traceSequentialSpec)
 bool specApplies(const TraceParams &p);
-hipError_t launchSeqSpec(const TraceParams &p, const TraceBuffers &b, hipStream_t stream);
+hipError_t launchSeqSpec(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream);
 // one wave per pass: slots = 1 (<= 64 triangles; reg: the register-resident REG variant) or 2 (<= 128)
 hipError_t launchSeqSingle(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream,
                            int slots, bool reg);

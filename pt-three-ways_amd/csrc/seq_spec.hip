@@ -39,11 +39,22 @@ struct alignas(16) SpecResult { // one per wave and round parity, in LDS
   int pad;
 };
 
+// CROSS (round 6): the NEXT pixel's camera ray and first hit, traced ahead by a wave that has no sub-sample
+// left in this pixel's last round(s) - see the kernel.  One record per tracing wave and pixel parity.
+struct alignas(16) PrimRec {
+  double o[3], d[3]; // the camera ray
+  double t;          // its nearest hit: distance (+inf: none) ...
+  uint32_t idxSign;  // ... combined primitive index << 1 | (det < epsilon), kMiss for none (packAnswer)
+  uint32_t pick;     // PICKS: the pick checksum's term of this call (call 0 of the sample)
+};
+static_assert(sizeof(PrimRec) == 64, "PrimRec layout");
+constexpr size_t kSpecPrimBytes = 2 * kSpecWaves * sizeof(PrimRec);
+
 __host__ __device__ inline size_t specLdsBytes(uint32_t ntri, uint32_t nmat, uint32_t nsph) {
   size_t n = 2 * kRingStride;                          // the ring
   n += kMtWords * sizeof(uint32_t);                    // raw generator state
   n += 2 * kSpecWaves * sizeof(SpecResult);            // results, double-buffered
-  n += 64 + kSeqCamBytes;                              // generator commands, the camera
+  n += 64 + kSeqCamBytes + kSpecPrimBytes;             // generator commands, the camera, the primary-ray records
   n = (n + 63) & ~static_cast<size_t>(63);
   n += static_cast<size_t>(nsph) * sizeof(SphereRec);
   n += static_cast<size_t>(ntri) * kTriCompactDoubles * sizeof(double);
@@ -53,7 +64,7 @@ __host__ __device__ inline size_t specLdsBytes(uint32_t ntri, uint32_t nmat, uin
   return n < floor ? floor : n;
 }
 
-template <bool PICKS>
+template <bool PICKS, bool CROSS>
 __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
     const TraceParams p, const double *__restrict__ triGeom, const SphereRec *__restrict__ spheres,
     const double *__restrict__ triCompact, const double *__restrict__ matTable,
@@ -73,6 +84,8 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
   // and read back for every pixel - see kSeqCamBytes)
   ptw_camera *camLds = reinterpret_cast<ptw_camera *>(ldsRaw + off);
   off += kSeqCamBytes;
+  PrimRec *primRecs = reinterpret_cast<PrimRec *>(ldsRaw + off); // [pixel parity][wave]
+  off += kSpecPrimBytes;
   off = (off + 63) & ~static_cast<size_t>(63);
   if (threadIdx.x < sizeof(ptw_camera) / sizeof(double))
     reinterpret_cast<double *>(camLds)[threadIdx.x] = reinterpret_cast<const double *>(&p.cam)[threadIdx.x];
@@ -210,44 +223,72 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
 #if PTW_PROFILE_PHASES
   unsigned long long stRounds = 0, stCommits = 0, stWork = 0, stWait = 0, stCommit = 0, stPrimary = 0;
   unsigned long long stOk1 = 0, stOk2a = 0, stOk3 = 0, stOk2b = 0, stIdle = 0;
+  unsigned long long stPrimTried = 0, stPrimTaken = 0, stCommitHist[5] = {0, 0, 0, 0, 0};
   const unsigned long long stT0 = __builtin_amdgcn_s_memtime();
 #endif
 
+  // CROSS: the wave (1..3) whose record holds THIS pixel's camera ray and first hit, traced during the previous
+  // pixel's last round at the stream position that pixel really ended at; 0 = none (trace it now)
+  int primWave = 0;
+  int px = static_cast<int>(p.pixBegin % static_cast<uint32_t>(w));
+  int py = static_cast<int>(p.pixBegin / static_cast<uint32_t>(w));
   for (uint32_t i = 0; i < p.pixCount; ++i) {
     const uint32_t pix = p.pixBegin + i;
-    const int px = static_cast<int>(pix % static_cast<uint32_t>(w));
-    const int py = static_cast<int>(pix / static_cast<uint32_t>(w));
     // ---- every wave: camera ray and first hit at the frontier (redundant, in parallel) ----
     PTW_T(tP0);
     ensureAhead();
-    ctx.setStream(fOff, fQ);
-    double r0, r1, r2 = 0, r3 = 0;
-    if (lens) {
-      ctx.draw4(r0, r1, r2, r3);
-    } else {
-      r0 = ctx.draw();
-      r1 = ctx.draw();
-    }
     const int camDraws = lens ? 4 : 2;
     d3 o, d;
-    cameraRay(*camLds, px, py, r0, r1, r2, r3, o, d);
     int sampleDraws = camDraws;
-    ctx.pickReset();
     uint32_t pickSum = 0, pickBase = 1; // the sample's pick checksum; intersect() calls committed so far
     d3 L = mk(0, 0, 0);
     bool traced = false;
     HitKey k0;
     k0.t = kInf, k0.idx = kMiss, k0.det = 0;
-    if (p.maxDepth > 0) {
-      k0 = ctx.intersect(o, d);
+#if PTW_PROFILE_PHASES
+    stPrimTaken += primWave != 0;
+#endif
+    if (CROSS && primWave != 0) {
+      // traced ahead (only ever with maxDepth > 0 and a fan-out: see below): one LDS round trip
+      const PrimRec &r = primRecs[(i & 1u) * kSpecWaves + primWave];
+      o = mk(r.o[0], r.o[1], r.o[2]), d = mk(r.d[0], r.d[1], r.d[2]);
+      k0.t = r.t;
+      const uint32_t pw = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(r.idxSign)));
+      k0.idx = pw == kMiss ? kMiss : (pw >> 1);
+      k0.det = (pw & 1u) ? -1.0 : 1.0; // (only its sign test is ever used)
       raysTotal++;
-      if (PICKS) pickSum = ctx.pickS2; // (the primary ray is call 0)
+      if (PICKS) pickSum = r.pick;
       if (uniformBool(k0.idx == kMiss)) {
         L = ld3(p.env);
       } else {
         traced = true;
       }
+    } else {
+      ctx.setStream(fOff, fQ);
+      double r0, r1, r2 = 0, r3 = 0;
+      if (lens) {
+        ctx.draw4(r0, r1, r2, r3);
+      } else {
+        r0 = ctx.draw();
+        r1 = ctx.draw();
+      }
+      cameraRay(*camLds, px, py, r0, r1, r2, r3, o, d);
+      ctx.pickReset();
+      if (p.maxDepth > 0) {
+        k0 = ctx.intersect(o, d);
+        raysTotal++;
+        if (PICKS) pickSum = ctx.pickS2; // (the primary ray is call 0)
+        if (uniformBool(k0.idx == kMiss)) {
+          L = ld3(p.env);
+        } else {
+          traced = true;
+        }
+      }
     }
+    primWave = 0;
+    // the next pixel (row-major; `pix` itself is only used for the optional per-sample outputs)
+    int pxNext = px + 1, pyNext = py;
+    if (pxNext == w) pxNext = 0, ++pyNext;
     advanceFrontier(camDraws);
 #if PTW_PROFILE_PHASES
     stPrimary += __builtin_amdgcn_s_memtime() - tP0;
@@ -275,6 +316,8 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
           m1 = 3 * best;
           m2 = secondN > 0 ? 3 * second : m1;
         }
+        // CROSS: what the pixel's last round looked like (read after the loop)
+        int lastJ = 0, lastCur = 0, lastD1 = 0, lastD2 = 0, lastD3 = 0, lastOne = 0;
         while (j < nSub) {
           ensureAhead();
           // ---- this wave's assignment: sub-sample j + ioff, stream position frontier + delta ----
@@ -317,6 +360,37 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
             mine.meta = static_cast<int>(ctx.words >> 1) | (refl ? 0x100 : 0) |
                         (static_cast<int>(ctx.rays) << 16);
             if (PICKS) mine.pad = static_cast<int>(ctx.pickS1 | (ctx.pickS2 << 16)); // (<= 9 calls of <= 127 primitives)
+          } else if (CROSS && myIdx == nSub && i + 1 < p.pixCount) {
+            // No sub-sample left for this wave, and its assignment is exactly "the sub-sample after the last
+            // one": that is the NEXT pixel's camera ray.  Trace it and its first hit at the stream position the
+            // assignment implies (this pixel ends `delta` draws after the round's frontier) into this wave's
+            // record; it is taken if the pixel really ends there (checked after the loop) - the same commit rule
+            // as for a sub-sample, so the value is the serial one bit for bit, and a wrong guess costs energy only.
+            const int np = fQ + delta; // delta + 4 camera draws stay within `ahead`
+            const bool wrap = np >= kMtDoubles;
+            ctx.setStream(wrap ? fOff ^ kRingStride : fOff, wrap ? np - kMtDoubles : np);
+            double r0, r1, r2 = 0, r3 = 0;
+            if (lens) {
+              ctx.draw4(r0, r1, r2, r3);
+            } else {
+              r0 = ctx.draw();
+              r1 = ctx.draw();
+            }
+            d3 no, nd;
+            cameraRay(*camLds, pxNext, pyNext, r0, r1, r2, r3, no, nd);
+            ctx.pickReset();
+            const HitKey nk = ctx.intersect(no, nd);
+#if PTW_PROFILE_PHASES
+            stPrimTried++;
+#endif
+            if (lane == 0) {
+              PrimRec &r = primRecs[((i + 1) & 1u) * kSpecWaves + wave];
+              r.o[0] = no.x, r.o[1] = no.y, r.o[2] = no.z;
+              r.d[0] = nd.x, r.d[1] = nd.y, r.d[2] = nd.z;
+              r.t = nk.t;
+              r.idxSign = packAnswer(nk);
+              r.pick = PICKS ? ctx.pickS2 : 0u;
+            }
           }
           SpecResult *slot = results + parity * kSpecWaves;
           if (lane == 0) slot[wave] = mine;
@@ -381,17 +455,31 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
             if (ok3) add(3, meta3);
             if (ok2b) add(2, meta2);
           }
+          if (CROSS) lastJ = j, lastCur = cur, lastD1 = d1, lastD2 = d2, lastD3 = d3v, lastOne = oneMode ? -1 : 0;
           j += nIdx;
           sampleDraws += cur;
           parity ^= 1;
           advanceFrontier(cur);
 #if PTW_PROFILE_PHASES
           stRounds++, stCommits += nIdx;
+          stCommitHist[nIdx]++;
           stOk1 -= ok1, stOk2a -= ok2a, stOk3 -= ok3, stOk2b -= ok2b, stIdle += !(myIdx < nSub);
           stWork += tW1 - tW0, stWait += tW2 - tW1, stCommit += __builtin_amdgcn_s_memtime() - tW2;
 #endif
         }
         L = result * p.invFirstBounce;
+        if (CROSS && i + 1 < p.pixCount) {
+          // Did a wave trace the next pixel's primary ray in the last round, and from where the pixel ended?
+          // Wave v did if its assignment was sub-sample index nSub (lastJ + ioff == nSub); it is right if its
+          // delta is what the round really consumed.  (The round that ends the pixel commits every remaining
+          // sub-sample, so `lastCur` is the distance from that round's frontier to the pixel's end.)
+          auto eq = [](int a, int b) { return ((a ^ b) - 1) >> 31; }; // a, b >= 0: -1 if equal
+          const int ioff2 = lastOne ? 3 : 1;
+          const int p1 = eq(lastJ + 1, nSub) & eq(lastD1, lastCur);
+          const int p2 = eq(lastJ + ioff2, nSub) & eq(lastD2, lastCur);
+          const int p3 = eq(lastJ + 2, nSub) & eq(lastD3, lastCur);
+          primWave = p1 ? 1 : (p2 ? 2 : (p3 ? 3 : 0));
+        }
       }
     }
     if (threadIdx.x == 0) {
@@ -401,6 +489,7 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
       if (words) words[static_cast<size_t>(pass) * p.npix + pix] = 2u * static_cast<unsigned>(sampleDraws);
       if (PICKS && picks) picks[static_cast<size_t>(pass) * p.npix + pix] = pickSum;
     }
+    px = pxNext, py = pyNext;
   }
 
   while (genState != 0) roundBarrier(0); // an outstanding block must be in the ring that gets parked
@@ -415,6 +504,10 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
     printf("SPEC wave %d: per round ok1=%.3f ok2a=%.3f ok3=%.3f ok2b=%.3f idle=%.3f\n", wave,
            (double)stOk1 / stRounds, (double)stOk2a / stRounds, (double)stOk3 / stRounds,
            (double)stOk2b / stRounds, (double)stIdle / stRounds);
+    printf("SPEC wave %d: rounds by sub-samples committed 1/2/3/4 = %.3f / %.3f / %.3f / %.3f of the rounds; next pixel's "
+           "primary ray traced ahead by this wave in %.3f rounds per pixel, pixels that started from such a record %.3f\n",
+           wave, (double)stCommitHist[1] / stRounds, (double)stCommitHist[2] / stRounds, (double)stCommitHist[3] / stRounds,
+           (double)stCommitHist[4] / stRounds, stPrimTried / n, stPrimTaken / n);
   }
 #endif
   if (threadIdx.x == 0) {
@@ -440,10 +533,13 @@ bool specApplies(const TraceParams &p) {
          seqLdsBytes(1, p.maxDepth, true, p.ntri, p.nmat, p.nsph) <= kLdsTableBudget;
 }
 
-hipError_t launchSeqSpec(const TraceParams &p, const TraceBuffers &b, hipStream_t stream) {
-  setVariant("traceSequentialSpec");
+hipError_t launchSeqSpec(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream) {
+  // (LaunchHints::seqSmallKernel == 3: round 5's form, without the next pixel's primary ray traced ahead)
+  const bool ahead = hints.seqSmallKernel != 3;
+  setVariant(ahead ? "traceSequentialSpec" : "traceSequentialSpec<no cross-pixel candidate>");
   const size_t lds = specLdsBytes(p.ntri, p.nmat, p.nsph);
-  auto kernel = b.picks ? traceSequentialSpec<true> : traceSequentialSpec<false>;
+  auto kernel = b.picks ? (ahead ? traceSequentialSpec<true, true> : traceSequentialSpec<true, false>)
+                        : (ahead ? traceSequentialSpec<false, true> : traceSequentialSpec<false, false>);
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,

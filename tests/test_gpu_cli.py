@@ -72,6 +72,9 @@ def test_sequential_kernel_variants_write_identical_bytes(pkg, tmp_path, scene, 
     # name -> (environment, --debug fields)
     variants = {"spec": ({}, {}), "reg": ({}, {"seq_small_kernel": 1}), "plain": ({}, {"seq_small_kernel": 0}),
                 "spec_bands": ({"PTW_STAGE_BUDGET_KB": "12"}, {}),
+                # round 5's form of the speculative kernel: without the next pixel's camera ray traced ahead
+                "spec_no_cross": ({}, {"seq_small_kernel": 3}),
+                "spec_no_cross_bands": ({"PTW_STAGE_BUDGET_KB": "12"}, {"seq_small_kernel": 3}),
                 }
     blobs = {}
     for name, (env, debug) in variants.items():

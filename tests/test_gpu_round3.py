@@ -548,11 +548,14 @@ SMALL_SCENE_CASES = [
 ]
 
 
-@pytest.mark.parametrize("kernel,debug", [("traceSequentialSpec", {}), ("traceSequential<1,1,lds,reg>", dict(seq_small_kernel=1)),
+@pytest.mark.parametrize("kernel,debug", [("traceSequentialSpec", {}),
+                                          ("traceSequentialSpec<no cross-pixel candidate>", dict(seq_small_kernel=3)),
+                                          ("traceSequential<1,1,lds,reg>", dict(seq_small_kernel=1)),
                                           ("traceSequential<1,1,lds,stack>", dict(seq_small_kernel=0))])
 def test_small_scene_kernels_match_oracle(pkg, ob, monkeypatch, kernel, debug):
-    """The three kernels for scenes of at most 64 triangles - four speculating waves per pass, one wave with
-    its (E, T) stack in scalar registers, one wave with the stack in LDS - against the oracle with pick
+    """The kernels for scenes of at most 64 triangles - four speculating waves per pass (with and without the
+    next pixel's camera ray traced ahead in a pixel's last round, round 6), one wave with its (E, T) stack in
+    scalar registers, one wave with the stack in LDS - against the oracle with pick
     checksums: closed and open scenes, every depth, odd fan-outs (the speculative kernel's general stratum
     path), primitive counts at the kernels' limits (64 triangles + 62 spheres + a shell = 127 primitives),
     streams parked and resumed between bands.  (These are the cases round 3's several-CUs-per-pass kernel was
