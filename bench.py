@@ -126,9 +126,10 @@ def parse_args():
     ap.add_argument("--strict-parity-passes", type=int, default=4)
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the extra measurement of the other RNG policy")
-    ap.add_argument("--accel", choices=["none", "bvh"], default="none",
-                    help="bvh: the SEPARATE accelerated mode (perpixel policy; same image, culled tests) - never "
-                         "the headline configuration")
+    ap.add_argument("--accel", choices=["none", "bvh", "prefilter"], default="none",
+                    help="the SEPARATE accelerated modes (perpixel policy; same image, other work): bvh = triangles "
+                         "culled by a hierarchy, prefilter = a conservative fp32 look before the fp64 test - never the "
+                         "headline configuration")
     ap.add_argument("--rows", default="",
                     help="BEGIN:END - time a sub-run of the frame (image rows [BEGIN, END) of the full-size frame; "
                          "under the sequential policy BEGIN must be 0: a prefix); the workload string says so")
@@ -259,9 +260,9 @@ class Shard:
             self.scaling = "strong" if args.scaling == "strong" else "weak"
             self.parallelism = "single GPU"
         self.rows = args.height
-        if args.accel == "bvh":
-            assert self.policy == pkg.RNG_PERPIXEL, "--accel bvh needs --policy perpixel"
-            extra = dict(extra, accel=pkg.ACCEL_BVH)
+        if args.accel != "none":
+            assert self.policy == pkg.RNG_PERPIXEL, "--accel needs --policy perpixel"
+            extra = dict(extra, accel=pkg.ACCEL_BVH if args.accel == "bvh" else pkg.ACCEL_PREFILTER)
         if args.rows:
             assert world == 1, "--rows times a sub-run on one GPU"
             r0, r1 = (int(v) for v in args.rows.split(":"))
@@ -630,6 +631,10 @@ def main():
     torch.cuda.synchronize()
     if policy == pkg.RNG_PERPIXEL and args.accel == "none":   # one kernel for every rank, chosen once, untimed
         shard.params.pix_kernel = agreed_pix_kernel(pkg, ctx, cam, shard.params, rank, use_dist, stream)
+    if policy == pkg.RNG_SEQUENTIAL and shard.params.samples_per_pixel > 0:
+        # untimed: scenes of at most 64 triangles with more passes than CUs (cfg5's per-GPU share) - the library
+        # times its two small-scene kernels once for this pass count; nothing happens for any other launch
+        ctx.calibrate(cam, shard.params, stream)
     if args.warmup > 0:
         timed_steps(shard, ctx, cam, [scratch], args.warmup, use_dist)
     elif shard.comm is not None and world > 1:

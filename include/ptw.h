@@ -27,7 +27,9 @@
 extern "C" {
 #endif
 
-#define PTW_ABI_VERSION 5
+/* 6 (round 6): PTW_ACCEL_PREFILTER and its known-answer entry ptw_scene_prefilter_records;
+ * ptw_debug_options.seq_small_kernel = 3; seq_pairing / gang_groups retired (refused, layout kept). */
+#define PTW_ABI_VERSION 6
 
 typedef enum ptw_status {
   PTW_OK = 0,
@@ -57,8 +59,14 @@ typedef enum ptw_rng_policy { PTW_RNG_SEQUENTIAL = 0, PTW_RNG_PERPIXEL = 1 } ptw
  *  BVH  — a SEPARATE, separately reported mode: triangles a ray cannot hit are culled by a
  *         bounding-volume hierarchy and the same Moller-Trumbore arithmetic runs on the rest, so
  *         every sample is bit-identical to the NONE result while the work (tests per ray) is not
- *         the reference's.  PTW_RNG_PERPIXEL only. */
-typedef enum ptw_accel { PTW_ACCEL_NONE = 0, PTW_ACCEL_BVH = 1 } ptw_accel;
+ *         the reference's.  PTW_RNG_PERPIXEL only.
+ *  PREFILTER — the other separate mode ("fp32 intersect"): every ray still looks at
+ *         every triangle (src/dod/Scene.cpp:62-98), but first in fp32 - two triangles per packed
+ *         instruction - and the reference's fp64 test runs only where the fp32 evaluation, with a
+ *         stated forward error bound, cannot PROVE that the fp64 test rejects.  Bit-identical samples
+ *         (a plain fp32 test would flip decisions); PTW_RNG_PERPIXEL only; refused with
+ *         PTW_ERR_UNSUPPORTED for scenes with coordinates beyond 1e12 (fp32 products could overflow). */
+typedef enum ptw_accel { PTW_ACCEL_NONE = 0, PTW_ACCEL_BVH = 1, PTW_ACCEL_PREFILTER = 2 } ptw_accel;
 
 /* Which of the PTW_RNG_PERPIXEL policy's two radiance kernels runs (same samples, same bytes;
  * which one is faster depends on how uniformly long the scene's paths are, which no host-side
@@ -193,6 +201,15 @@ int ptw_scene_build_named(ptw_scene *scene, const char *name, const char *scenes
                           int32_t width, int32_t height, ptw_camera *camera_out);
 /* Borrowed view, valid until the scene is modified or destroyed. */
 int ptw_scene_view_of(const ptw_scene *scene, ptw_scene_view *out);
+/* Known-answer hook for PTW_ACCEL_PREFILTER (host only, no device): the fp32 records the prefilter kernel
+ * reads - one per PAIR of triangles (2k, 2k + 1), 22 floats: v0 / e1 / e2 component-interleaved (x of A, x of
+ * B, y of A, ...), then the error-bound coefficients EA(A, B), EB(A, B) with E = EA + |ray origin|_inf * EB
+ * (the geometry rounded to nearest, the coefficients rounded up).  Writes min(capacity_floats, 22 *
+ * ceil(ntri / 2)) floats, *needed_floats = the full size, *usable = 0 when the mode refuses the scene
+ * (a coordinate that is not finite or beyond 1e12).  The tests check the conservativeness of the
+ * criterion with these very records (src/dod/Scene.cpp:62-98 is what must never be contradicted). */
+int ptw_scene_prefilter_records(const ptw_scene *scene, float *out, uint64_t capacity_floats,
+                                uint64_t *needed_floats, int32_t *usable);
 
 /* ---- Camera ctor / setFocus, src/math/Camera.h:40-51 ------------------------------------ */
 int ptw_camera_look_at(const double eye[3], const double look_at[3], const double up[3],
@@ -241,6 +258,8 @@ typedef struct ptw_debug_options {
   int32_t fail_collective;      /*   shard that fails its set-up / its collective call / reports      */
   int32_t silent_shard;         /*   success WITHOUT entering the collective (the watchdog ends it)   */
   int32_t trace;                /* 1: ptw_context_calibrate prints its two timings to stderr          */
+  int32_t intersect_accel;      /* ptw_context_intersect (the known-answer entry): 0 = the brute-force
+                                   search, PTW_ACCEL_PREFILTER = through the fp32 prefilter - same hits */
   /* Pick checksum (parity instrumentation, PTW_RNG_SEQUENTIAL only): a DEVICE pointer to
    * [pass][y][x] uint32 receiving, per sample, sum over the sample's intersect() calls r = 0, 1, ...
    * in the reference's call order of (r + 1) * (combined primitive index + 1) mod 2^32, a miss
@@ -313,6 +332,10 @@ int ptw_context_render(ptw_context *ctx, const ptw_camera *camera,
  * same kernel.  ptw_render / ptw_render_ex (synchronous calls) do this themselves for renders of
  * 16 M samples or more.  Under PTW_RNG_SEQUENTIAL / the accelerated mode: PTW_PIX_KERNEL_AUTO, no
  * trial. */
+/* (Round 6: under PTW_RNG_SEQUENTIAL the same call times the two small-scene kernels - one wave per pass
+ * against four speculating waves - when the scene has at most 64 triangles and the launch between one and six
+ * passes per compute unit, where which one wins depends on the scene; the context remembers the winner for this
+ * scene, camera, frame shape and pass count, *kernel_out is PTW_PIX_KERNEL_AUTO.  A no-op for every other launch.) */
 int ptw_context_calibrate(ptw_context *ctx, const ptw_camera *camera,
                           const ptw_render_params *params, void *hip_stream, int32_t *kernel_out);
 /* Tests / A-B runs only: the context's renders from now on follow `options` (copied; NULL restores
@@ -332,6 +355,23 @@ typedef struct ptw_kernel_stats {
 int ptw_context_enable_stats(ptw_context *ctx, int32_t enable);
 /* Synchronises the events it reads. */
 int ptw_context_get_stats(ptw_context *ctx, ptw_kernel_stats *out, int32_t reset);
+
+/* Which kernel would run?  The dispatch rules of the library (csrc/dispatch.hip and the family launchers) for
+ * a scene of the given size and a launch of `samples_per_pixel` passes, WITHOUT a device or a launch: writes
+ * the kernel's name - the string ptw_kernel_stats.trace_kernel reports after a real render - into `out`.
+ * `debug` may be NULL (the dispatcher decides).  scripts/dispatch_sweep.py and the CPU tests use it. */
+typedef struct ptw_dispatch_query {
+  uint32_t num_triangles, num_spheres, num_materials;
+  int32_t max_depth;         /* RenderParams::maxDepth (5)                                        */
+  int32_t samples_per_pixel; /* passes of the launch                                              */
+  int32_t rng_policy;        /* ptw_rng_policy                                                    */
+  int32_t accel;             /* ptw_accel                                                         */
+  int32_t pix_kernel;        /* ptw_pix_kernel (AUTO = the uncalibrated default)                  */
+  int32_t compute_units;     /* 0: the current device's count (256 when there is no device)       */
+  int32_t reserved[3];
+} ptw_dispatch_query;
+int ptw_dispatch_plan(const ptw_dispatch_query *query, const struct ptw_debug_options *debug, char *out,
+                      size_t capacity);
 
 /* Batch form of Scene::intersect (src/dod/Scene.cpp:115-122) for known-answer tests:
  * rays[n][6] = origin, direction (direction already normalised) -> hit[n]: distance (or -1

@@ -27,6 +27,7 @@ RNG_SEQUENTIAL = 0
 RNG_PERPIXEL = 1
 ACCEL_NONE = 0
 ACCEL_BVH = 1
+ACCEL_PREFILTER = 2
 PIX_KERNEL_AUTO = 0
 PIX_KERNEL_LOCKSTEP = 1
 PIX_KERNEL_PERSISTENT = 2
@@ -124,7 +125,15 @@ class DebugOptions(C.Structure):
                 ("seq_small_kernel", C.c_int32), ("seq_units", C.c_int32 * 3),
                 ("pix_samples_per_lane", C.c_int32), ("pix_waves_per_simd", C.c_int32),
                 ("gang_groups", C.c_int32), ("fail_shard", C.c_int32), ("fail_collective", C.c_int32),
-                ("silent_shard", C.c_int32), ("trace", C.c_int32), ("d_picks", C.c_void_p)]
+                ("silent_shard", C.c_int32), ("trace", C.c_int32), ("intersect_accel", C.c_int32), ("d_picks", C.c_void_p)]
+
+
+class DispatchQuery(C.Structure):
+    """ptw_dispatch_query (include/ptw.h)."""
+    _fields_ = [("num_triangles", C.c_uint32), ("num_spheres", C.c_uint32), ("num_materials", C.c_uint32),
+                ("max_depth", C.c_int32), ("samples_per_pixel", C.c_int32), ("rng_policy", C.c_int32),
+                ("accel", C.c_int32), ("pix_kernel", C.c_int32), ("compute_units", C.c_int32),
+                ("reserved", C.c_int32 * 3)]
 
 
 class RenderOptions(C.Structure):
@@ -165,6 +174,8 @@ _sig("ptw_scene_load_obj_text", C.c_int, C.c_void_p, C.c_char_p, C.c_char_p)
 _sig("ptw_scene_build_named", C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32,
      C.POINTER(Camera))
 _sig("ptw_scene_view_of", C.c_int, C.c_void_p, C.POINTER(SceneView))
+_sig("ptw_dispatch_plan", C.c_int, C.POINTER(DispatchQuery), C.c_void_p, C.c_char_p, C.c_size_t)
+_sig("ptw_scene_prefilter_records", C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int32))
 _sig("ptw_camera_look_at", C.c_int, _D3, _D3, _D3, C.c_int32, C.c_int32, C.c_double,
      C.POINTER(Camera))
 _sig("ptw_camera_set_focus", C.c_int, C.POINTER(Camera), _D3, C.c_double)
@@ -239,6 +250,20 @@ def debug_options(**overrides) -> DebugOptions:
         else:
             setattr(d, k, int(v))
     return d
+
+
+def dispatch_plan(num_triangles: int, num_spheres: int = 1, samples_per_pixel: int = 256, rng_policy: int = 0,
+                  accel: int = 0, pix_kernel: int = 0, compute_units: int = 256, max_depth: int = 5,
+                  num_materials: int = 4, **debug) -> str:
+    """ptw_dispatch_plan: the kernel the dispatch rules pick for a scene of this size and a launch of this many
+    passes - no device, no launch.  `debug`: ptw_debug_options fields."""
+    q = DispatchQuery(num_triangles=num_triangles, num_spheres=num_spheres, num_materials=num_materials,
+                      max_depth=max_depth, samples_per_pixel=samples_per_pixel, rng_policy=rng_policy, accel=accel,
+                      pix_kernel=pix_kernel, compute_units=compute_units)
+    out = C.create_string_buffer(128)
+    d = debug_options(**debug) if debug else None
+    _check(lib.ptw_dispatch_plan(C.byref(q), C.byref(d) if d is not None else None, out, 128))
+    return out.value.decode()
 
 
 def material(kind: str = "default", colour=(0, 0, 0), *args) -> Material:
@@ -322,6 +347,14 @@ class Scene:
         _check(lib.ptw_scene_view_of(self._h, C.byref(v)))
         return v
 
+    def prefilter_records(self):
+        """PTW_ACCEL_PREFILTER's fp32 pair records (ptw_scene_prefilter_records): ([npairs, 22] float32, usable)."""
+        need, usable = C.c_uint64(0), C.c_int32(0)
+        _check(lib.ptw_scene_prefilter_records(self._h, None, 0, C.byref(need), C.byref(usable)))
+        out = np.zeros(need.value, dtype=np.float32)
+        _check(lib.ptw_scene_prefilter_records(self._h, out.ctypes.data, need.value, C.byref(need), C.byref(usable)))
+        return out.reshape(-1, 22), bool(usable.value)
+
     def arrays(self):
         """Copies of the flattened arrays (for tests)."""
         v = self.view()
@@ -394,6 +427,15 @@ class Comm:
         h = C.c_void_p()
         _check(lib.ptw_comm_create(buf, world_size, rank, device, C.byref(h)))
         return cls(h)
+
+    @classmethod
+    def create_all(cls, devices) -> "list[Comm]":
+        """One communicator per listed device inside this process (ptw_comm_create_all = ncclCommInitAll)."""
+        n = len(devices)
+        dev = (C.c_int32 * n)(*[int(d) for d in devices])
+        arr = (C.c_void_p * n)()
+        _check(lib.ptw_comm_create_all(n, dev, arr))
+        return [cls(C.c_void_p(arr[i])) for i in range(n)]
 
     @classmethod
     def create_loopback(cls, world_size: int, device: int = 0) -> "list[Comm]":

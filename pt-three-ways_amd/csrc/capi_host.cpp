@@ -4,6 +4,8 @@
 
 #include "../host/framebuffer.h"
 #include "../host/obj_loader.h"
+#include "../host/precompute.h"
+#include "../host/prefilter.h"
 #include "../host/scenes.h"
 
 #include <cstring>
@@ -179,6 +181,22 @@ int ptw_scene_view_of(const ptw_scene *scene, ptw_scene_view *out) {
   if (!scene || !out) return invalid("null pointer");
   *out = scene->builder.view();
   return PTW_OK;
+}
+
+int ptw_scene_prefilter_records(const ptw_scene *scene, float *out, uint64_t capacity_floats,
+                                uint64_t *needed_floats, int32_t *usable) {
+  if (!scene || (!out && capacity_floats)) return invalid("null pointer");
+  PTW_GUARD_BEGIN
+  const ptw_scene_view view = scene->builder.view();
+  const ptw::DeviceSceneData data = ptw::precomputeScene(view); // (v0, e1, e2 exactly as the device gets them)
+  const ptw::PrefilterData pre = ptw::buildPrefilter(data.triGeom.data(), view.num_triangles, view.sph_centre_radius, view.num_spheres);
+  const uint64_t full = view.num_triangles ? pre.pairs.size() : 0;
+  if (needed_floats) *needed_floats = full;
+  if (usable) *usable = pre.usable ? 1 : 0;
+  const uint64_t n = full < capacity_floats ? full : capacity_floats;
+  for (uint64_t i = 0; i < n; ++i) out[i] = pre.pairs[i];
+  return PTW_OK;
+  PTW_GUARD_END
 }
 
 int ptw_camera_look_at(const double eye[3], const double look_at[3], const double up[3],

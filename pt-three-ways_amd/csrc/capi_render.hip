@@ -7,6 +7,7 @@
 #include "ptw_kernels.h"
 
 #include "../host/bvh.h"
+#include "../host/prefilter.h"
 #include "../host/precompute.h"
 
 #include <algorithm>
@@ -77,6 +78,13 @@ struct ptw_context {
   DeviceArray<BvhNode> bvhNodes;
   DeviceArray<double> bvhLeafGeom;
   DeviceArray<uint32_t> bvhLeafIndex;
+  // accelerated mode (PTW_ACCEL_PREFILTER): the fp32 pair records, built with the scene
+  DeviceArray<float> triPacked;
+  bool prefilterUsable = false;
+  // SEQUENTIAL, scenes of at most 64 triangles, more passes than CUs: the small-scene kernel a timed trial chose
+  // (ptw_debug_options.seq_small_kernel's values 1 / 2; 0 = none) and what it was measured for
+  int seqSmallChoice = 0;
+  uint64_t seqSmallChoiceKey = 0;
   DeviceArray<double> specState; // parked stream rings of traceSequentialSpec
   uint32_t nmat = 0;
   DeviceArray<uint32_t> mtState, mtPos;
@@ -180,7 +188,8 @@ void validate(const ptw_render_params &p) {
   if (p.row_stride < 0 || p.row_phase < 0 || (p.row_stride > 1 && p.row_phase >= p.row_stride) ||
       (p.row_stride <= 1 && p.row_phase != 0))
     throw std::invalid_argument("bad row_stride / row_phase");
-  if (p.accel != PTW_ACCEL_NONE && p.accel != PTW_ACCEL_BVH) throw std::invalid_argument("unknown accel mode");
+  if (p.accel != PTW_ACCEL_NONE && p.accel != PTW_ACCEL_BVH && p.accel != PTW_ACCEL_PREFILTER)
+    throw std::invalid_argument("unknown accel mode");
   if (p.pix_kernel != PTW_PIX_KERNEL_AUTO && p.pix_kernel != PTW_PIX_KERNEL_LOCKSTEP &&
       p.pix_kernel != PTW_PIX_KERNEL_PERSISTENT)
     throw std::invalid_argument("unknown pix_kernel");
@@ -188,6 +197,7 @@ void validate(const ptw_render_params &p) {
     throw DeviceError(PTW_ERR_UNSUPPORTED,
                       "the accelerated mode needs PTW_RNG_PERPIXEL (the SEQUENTIAL kernels search the "
                       "scene cooperatively, a lane per primitive)");
+
   // Under PTW_RNG_SEQUENTIAL the pixels of a pass share one stream, consumed in row-major order: the
   // only window that means anything is a PREFIX of the frame (rows [0, row_end): exactly what the
   // full render produces for those rows - used for timed sub-runs of very large frames).
@@ -273,6 +283,57 @@ uint64_t pixChoiceKeyOf(const ptw_context &ctx, const TraceParams &t, const RowS
   return key;
 }
 
+// ... and of the SEQUENTIAL small-scene choice: the scene, the camera, the frame's shape AND the pass count
+uint64_t seqSmallChoiceKeyOf(const ptw_context &ctx, const TraceParams &t) {
+  RowSet none;
+  none.first = 0, none.count = 0, none.stride = static_cast<int>(t.npass);
+  return pixChoiceKeyOf(ctx, t, none) ^ 0x9e3779b97f4a7c15ull;
+}
+
+// The timed trial of the two small-scene SEQUENTIAL kernels (blocks until it has run): the first pixels of the
+// frame from freshly seeded generators, each kernel once; the render that follows seeds again.
+int calibrateSeqSmall(ptw_context &ctx, const TraceParams &t, const TraceBuffers &b, uint32_t pixTotal, size_t stageDoubles,
+                      hipStream_t stream) {
+  LaunchHints hints = ctx.hints();
+  if (!seqSmallKernelIsOpen(t, hints) || !b.specState) return 0;
+  TraceParams tt = t;
+  tt.pixBegin = 0;
+  tt.firstBand = 1;
+  tt.pixCount = static_cast<uint32_t>(std::min<uint64_t>(std::min<uint32_t>(pixTotal, 192), stageDoubles / (3ull * t.npass)));
+  if (tt.pixCount < 16) return 0; // (too small a frame to tell, or to matter)
+  TraceBuffers bb = b;
+  bb.rays = nullptr, bb.words = nullptr, bb.picks = nullptr;
+  hipEvent_t ev[3];
+  for (auto &e : ev) check(hipEventCreate(&e), "hipEventCreate");
+  float ms[2] = {0, 0};
+  try {
+    for (int warm = 1; warm >= 0; --warm) { // first pass: code objects loaded, tiny; second: timed
+      TraceParams run = tt;
+      if (warm) run.pixCount = 4;
+      check(hipEventRecord(ev[0], stream), "hipEventRecord");
+      hints.seqSmallKernel = 1;
+      check(launchTraceSequential(run, bb, hints, stream), "trial launch");
+      check(hipEventRecord(ev[1], stream), "hipEventRecord");
+      hints.seqSmallKernel = 2;
+      check(launchTraceSequential(run, bb, hints, stream), "trial launch");
+      check(hipEventRecord(ev[2], stream), "hipEventRecord");
+    }
+    check(hipEventSynchronize(ev[2]), "hipEventSynchronize");
+    check(hipEventElapsedTime(&ms[0], ev[0], ev[1]), "hipEventElapsedTime");
+    check(hipEventElapsedTime(&ms[1], ev[1], ev[2]), "hipEventElapsedTime");
+  } catch (...) {
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    throw;
+  }
+  for (auto &e : ev) (void)hipEventDestroy(e);
+  ctx.seqSmallChoiceKey = seqSmallChoiceKeyOf(ctx, t);
+  ctx.seqSmallChoice = ms[0] <= ms[1] ? 1 : 2;
+  if (ctx.debug.trace)
+    std::fprintf(stderr, "ptw: SEQUENTIAL small-scene trial (%u pixels x %u passes): one wave per pass %.3f ms, four speculating "
+                         "waves %.3f ms -> %s\n", tt.pixCount, tt.npass, ms[0], ms[1], ctx.seqSmallChoice == 1 ? "one wave" : "speculative");
+  return ctx.seqSmallChoice;
+}
+
 // What PTW_PIX_KERNEL_AUTO means for this launch: the calibrated choice, else the persistent kernel.
 int resolvePixKernel(const ptw_context &ctx, const ptw_render_params &p, const TraceParams &t, const RowSet &rows) {
   if (p.pix_kernel != PTW_PIX_KERNEL_AUTO) return p.pix_kernel;
@@ -344,6 +405,10 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   if (calibrate) *calibrate = kPixKernelAuto;
   validate(p);
   if (!ctx.haveScene) throw std::invalid_argument("no scene set on this context");
+  if (p.accel == PTW_ACCEL_PREFILTER && !(ctx.prefilterUsable && prefilterAcceptsOrigin(cam.centre, cam.aperture_radius)))
+    throw DeviceError(PTW_ERR_UNSUPPORTED,
+                      "PTW_ACCEL_PREFILTER: the scene (or the camera) has coordinates that are not finite or beyond 1e12 - "
+                      "the fp32 prefilter's products could overflow (host/prefilter.h)");
   ctx.activate();
   const uint32_t npass = static_cast<uint32_t>(p.samples_per_pixel);
   if (npass == 0) return;
@@ -372,7 +437,7 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   if (minBands > 1) bandPix = std::min<uint64_t>(bandPix, (pixTotal + minBands - 1) / minBands);
   bandPix = std::max<uint64_t>(bandPix, 64);
   bandPix = std::min<uint64_t>(bandPix, pixTotal);
-  const LaunchHints hints = ctx.hints();
+  LaunchHints hints = ctx.hints();
   // Kernels that left the tree (LAB.md: the paired two-master form, several CUs per pass): asking for one is
   // an error, not a silent run of the default dispatch under the old label.
   if (ctx.debug.seq_pairing == 1 || ctx.debug.gang_groups > 0)
@@ -391,7 +456,6 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
     check(hipDeviceSynchronize(), "hipDeviceSynchronize");
   }
 
-  if (calibrate && sequential) return;
   if (sequential) {
     // std::mt19937 rng(seed + curSample++), Scene.cpp:211: seed the generators on the host
     if (ctx.uploadsDone) // an earlier render's upload may still be reading the host vectors
@@ -427,6 +491,7 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   b.bvhNodes = ctx.bvhNodes.ptr;
   b.bvhLeafGeom = ctx.bvhLeafGeom.ptr;
   b.bvhLeafIndex = ctx.bvhLeafIndex.ptr;
+  b.triPacked = ctx.triPacked.ptr;
 
   auto timedLaunch = [&](bool trace, auto &&launch) {
     if (!ctx.statsEnabled) {
@@ -444,10 +509,16 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   };
 
   if (calibrate) {
-    *calibrate = calibratePixKernel(ctx, t, b, rows, ctx.stage.capacity, stream);
+    if (sequential)
+      (void)calibrateSeqSmall(ctx, t, b, pixTotal, ctx.stage.capacity, stream); // (*calibrate stays AUTO: not a PERPIXEL choice)
+    else
+      *calibrate = calibratePixKernel(ctx, t, b, rows, ctx.stage.capacity, stream);
     return;
   }
   if (!sequential) t.pixKernel = resolvePixKernel(ctx, p, t, rows);
+  // a measured small-scene choice for exactly this scene, camera, frame shape and pass count
+  if (sequential && ctx.seqSmallChoice != 0 && seqSmallKernelIsOpen(t, hints) && ctx.seqSmallChoiceKey == seqSmallChoiceKeyOf(ctx, t))
+    hints.seqSmallKernel = ctx.seqSmallChoice;
 
   uint64_t done = 0;
   for (uint32_t begin = 0; begin < pixTotal;) {
@@ -522,6 +593,9 @@ int ptw_context_set_scene(ptw_context *ctx, const ptw_scene_view *scene) {
   ctx->bvhNodes.upload(bvh.nodes.data(), bvh.nodes.size(), nullptr);
   ctx->bvhLeafGeom.upload(bvh.leafGeom.data(), bvh.leafGeom.size(), nullptr);
   ctx->bvhLeafIndex.upload(bvh.leafIndex.data(), bvh.leafIndex.size(), nullptr);
+  const PrefilterData pre = buildPrefilter(data.triGeom.data(), scene->num_triangles, scene->sph_centre_radius, scene->num_spheres);
+  ctx->triPacked.upload(pre.pairs.data(), pre.pairs.size(), nullptr);
+  ctx->prefilterUsable = pre.usable;
   check(hipStreamSynchronize(nullptr), "scene upload");
   ctx->ntri = scene->num_triangles;
   ctx->nsph = scene->num_spheres;
@@ -604,6 +678,45 @@ int ptw_context_get_stats(ptw_context *ctx, ptw_kernel_stats *out, int32_t reset
   PTW_GUARD_END
 }
 
+int ptw_dispatch_plan(const ptw_dispatch_query *q, const ptw_debug_options *debug, char *out, size_t capacity) {
+  if (!q || !out || capacity == 0) return invalid("null pointer");
+  PTW_GUARD_BEGIN
+  if (q->rng_policy != PTW_RNG_SEQUENTIAL && q->rng_policy != PTW_RNG_PERPIXEL) throw std::invalid_argument("unknown rng_policy");
+  if (q->accel != PTW_ACCEL_NONE && q->rng_policy != PTW_RNG_PERPIXEL)
+    throw DeviceError(PTW_ERR_UNSUPPORTED, "the accelerated modes need PTW_RNG_PERPIXEL");
+  if (q->samples_per_pixel <= 0) throw std::invalid_argument("samples_per_pixel must be positive");
+  ptw_context probe; // (never touches a device: only its debug -> hints translation is used)
+  if (debug) probe.debug = *debug;
+  LaunchHints hints = probe.hints();
+  hints.dryRun = true;
+  hints.cus = q->compute_units;
+  TraceParams t;
+  std::memset(&t, 0, sizeof t);
+  t.ntri = q->num_triangles, t.nsph = q->num_spheres, t.nmat = q->num_materials;
+  t.maxDepth = q->max_depth;
+  t.fbU = t.fbV = 4;
+  t.width = t.height = 1024;
+  t.npix = 1024u * 1024u;
+  t.pixCount = t.npix;
+  t.npass = static_cast<uint32_t>(q->samples_per_pixel);
+  t.rngPolicy = q->rng_policy;
+  t.accel = q->accel;
+  t.pixKernel = q->pix_kernel == PTW_PIX_KERNEL_LOCKSTEP ? kPixKernelLockstep : kPixKernelPersistent;
+  TraceBuffers b;
+  std::memset(&b, 0, sizeof b);
+  static double notNull;
+  b.specState = &notNull; // (the dispatcher only asks whether the ring's parking space exists)
+  const char *variant = "";
+  const hipError_t e = q->rng_policy == PTW_RNG_SEQUENTIAL ? launchTraceSequential(t, b, hints, nullptr, &variant)
+                                                           : launchTracePerPixel(t, b, hints, nullptr, &variant);
+  if (e != hipSuccess) throw DeviceError(PTW_ERR_HIP, "dispatch plan");
+  const size_t n = std::strlen(variant);
+  if (n + 1 > capacity) throw std::invalid_argument("ptw_dispatch_plan: buffer too small");
+  std::memcpy(out, variant, n + 1);
+  return PTW_OK;
+  PTW_GUARD_END
+}
+
 int ptw_context_intersect(ptw_context *ctx, const double *rays, uint64_t n, double *hits_out) {
   if (!ctx || (!rays && n) || (!hits_out && n)) return invalid("null pointer");
   PTW_GUARD_BEGIN
@@ -627,6 +740,16 @@ int ptw_context_intersect(ptw_context *ctx, const double *rays, uint64_t n, doub
   b.spheres = ctx->spheres.ptr;
   b.triCompact = ctx->triCompact.ptr;
   b.matTable = ctx->matTable.ptr;
+  // (tests: the same search through the fp32 prefilter of PTW_ACCEL_PREFILTER)
+  if (ctx->debug.intersect_accel == PTW_ACCEL_PREFILTER) {
+    bool ok = ctx->prefilterUsable;
+    for (uint64_t i = 0; i < n && ok; ++i) ok = prefilterAcceptsOrigin(rays + 6 * i, 0.0);
+    if (!ok) throw DeviceError(PTW_ERR_UNSUPPORTED, "PTW_ACCEL_PREFILTER: coordinates (scene or ray origins) beyond 1e12");
+    t.accel = PTW_ACCEL_PREFILTER;
+    b.triPacked = ctx->triPacked.ptr;
+  } else if (ctx->debug.intersect_accel != PTW_ACCEL_NONE) {
+    throw std::invalid_argument("ptw_debug_options.intersect_accel: PTW_ACCEL_NONE or PTW_ACCEL_PREFILTER");
+  }
   check(launchIntersectBatch(t, b, dRays.ptr, n, dHits.ptr, nullptr), "intersect launch");
   check(hipMemcpy(hits_out, dHits.ptr, n * 9 * sizeof(double), hipMemcpyDeviceToHost), "D2H");
   // the kernel reports the combined primitive index; the ABI promises the material index
@@ -681,6 +804,14 @@ bool wantsCalibration(const ptw_render_params &p) {
                            static_cast<uint64_t>(std::max(0, p.samples_per_pixel));
   return samples >= kCalibrateFromSamples;
 }
+// ... and a SEQUENTIAL render of that size whose pass count may leave the small-scene kernel open (whether it
+// does depends on the scene: ptw_context_calibrate looks, and does nothing when it does not)
+bool wantsSeqCalibration(const ptw_render_params &p) {
+  if (p.rng_policy != PTW_RNG_SEQUENTIAL) return false;
+  const uint64_t samples = static_cast<uint64_t>(rowsOf(p).count) * static_cast<uint64_t>(p.width) *
+                           static_cast<uint64_t>(std::max(0, p.samples_per_pixel));
+  return samples >= kCalibrateFromSamples;
+}
 
 // One device's share of a ptw_render_ex call: its own context (one scene upload), its own
 // stream, device-resident framebuffer.
@@ -731,6 +862,8 @@ void renderSingle(const ptw_scene_view &scene, const ptw_camera &camera,
   // the 5 % steps of the reference's Progressifier, `min_updates` for snapshots.
   const int minBands = opt.update ? (opt.min_updates > 0 ? opt.min_updates : 16) : (opt.progress ? 20 : 0);
   ptw_render_params rp = params;
+  if (wantsSeqCalibration(rp))
+    if (int rc = ptw_context_calibrate(ctx.get(), &camera, &rp, nullptr, nullptr); rc != PTW_OK) throw DeviceError(rc, ptw_last_error());
   if (wantsCalibration(rp)) {
     int32_t choice = PTW_PIX_KERNEL_AUTO;
     if (int rc = ptw_context_calibrate(ctx.get(), &camera, &rp, nullptr, &choice); rc != PTW_OK)

@@ -50,6 +50,12 @@ int deviceCus() {
   return cus;
 }
 
+bool seqSmallKernelIsOpen(const TraceParams &p, const LaunchHints &hints) {
+  const uint32_t cus = static_cast<uint32_t>(cusFor(hints));
+  return p.rngPolicy == PTW_RNG_SEQUENTIAL && p.ntri <= 64 && hints.seqSmallKernel == -1 && specApplies(p) && p.npass > cus &&
+         p.npass <= 6 * cus;
+}
+
 namespace {
 hipError_t dispatchSequential(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream) {
   const uint32_t n = p.ntri;
@@ -63,7 +69,7 @@ hipError_t dispatchSequential(const TraceParams &p, const TraceBuffers &b, const
     // ... and, by default, with the fan-out traced speculatively by four waves.  The speculative
     // kernel spends a whole CU on a pass.  That pays while there are at most as many passes as CUs;
     // with more, one wave per pass on every SIMD is the better use of the chip.
-    const int cus = deviceCus();
+    const int cus = cusFor(hints);
     const bool forced = hints.seqSmallKernel == 2 || hints.seqSmallKernel == 3; // whatever the pass count
     if (reg && hints.seqSmallKernel != 1 && b.specState && (forced || p.npass <= static_cast<uint32_t>(cus)))
       return launchSeqSpec(p, b, hints, stream);
@@ -77,7 +83,7 @@ hipError_t dispatchSequential(const TraceParams &p, const TraceBuffers &b, const
   // passes 1.43 -> 2.02; with no more passes than CUs it would only leave CUs empty).
   // LaunchHints::seqTwoMasters 0 / 1: never / always.
   const bool mm = hints.seqTwoMasters == 0 || hints.seqTwoMasters == 1 ? hints.seqTwoMasters == 1
-                                                                      : p.npass > static_cast<uint32_t>(deviceCus());
+                                                                      : p.npass > static_cast<uint32_t>(cusFor(hints));
   return mm ? launchSeqTwoMasters(p, b, hints, stream) : launchSeqOneMaster(p, b, hints, stream);
 }
 } // namespace

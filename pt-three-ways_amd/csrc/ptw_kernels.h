@@ -112,6 +112,8 @@ struct TraceBuffers {
   const void *bvhNodes;
   const double *bvhLeafGeom;
   const uint32_t *bvhLeafIndex;
+  // prefilter mode (host/prefilter.h): [(ntri + 1) / 2][22] floats, two triangles per record
+  const float *triPacked;
 };
 
 // What ptw_debug_options asks of the launchers (include/ptw.h; the defaults leave every decision to
@@ -120,12 +122,22 @@ struct LaunchHints {
   int seqTwoMasters = -1, seqLdsTables = -1, seqSmallKernel = -1;
   int seqUnits[3] = {0, 0, 0};
   int pixSamplesPerLane = 0, pixWavesPerSimd = 0;
+  // ptw_dispatch_plan: name the kernel the dispatch rules pick without launching anything (no device needed),
+  // for `cus` compute units (0 = the current device's count)
+  bool dryRun = false;
+  int cus = 0;
 };
 
 // SEQUENTIAL policy: one workgroup per pass walks the band's pixels in row-major order.
 // `variant` (may be null) receives the name of the kernel variant that was launched.
 hipError_t launchTraceSequential(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints,
                                  hipStream_t stream, const char **variant = nullptr);
+// Scenes of at most 64 triangles with MORE passes than compute units: the four-wave speculative kernel (a CU
+// per pass, the workgroups in turns) or one wave per pass (the SIMDs fill up as the pass count grows)?  Which one
+// wins between one and about six passes per CU depends on how often the scene's speculation commits (closed
+// scenes: four sub-samples per round; Cornell: two) - round 6's sweep measured 1.7x either way.  True when the
+// dispatch rules leave that open for this launch (then capi_render.hip times both once: ptw_context_calibrate).
+bool seqSmallKernelIsOpen(const TraceParams &p, const LaunchHints &hints);
 // PERPIXEL policy: one lane per (pass, pixel) sample.
 hipError_t launchTracePerPixel(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints,
                                hipStream_t stream, const char **variant = nullptr);

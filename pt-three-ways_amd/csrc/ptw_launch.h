@@ -26,6 +26,7 @@ const char *lastVariant();
 
 constexpr size_t kLdsTableBudget = 150 * 1024; // bytes of LDS we are willing to spend on shading tables
 int deviceCus();
+inline int cusFor(const LaunchHints &hints) { return hints.cus > 0 ? hints.cus : deviceCus(); }
 
 // ---- SEQUENTIAL families (each defined in the file named above) --------------------------------------------
 // the scenes the register-resident kernels handle (REG variant of the single-wave kernel, traceSequentialSpec)

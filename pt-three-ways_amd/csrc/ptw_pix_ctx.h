@@ -35,8 +35,89 @@ struct BvhNodeDev {
 };
 constexpr int kBvhStack = 32;
 
-template <bool BVH>
+// How PixCtxT::intersect walks the triangles: every one in fp64 (the reference's brute force); the BVH-culled
+// form; every one in fp32 first, two per instruction, and in fp64 only where fp32 cannot prove a rejection.
+constexpr int kPixBrute = 0, kPixBvh = 1, kPixPrefilter = 2;
+
+// The fp32 data of two triangles for the prefilter (host/prefilter.h: component-interleaved, then the
+// error-bound coefficients), through scalar loads like the fp64 triangles.
+typedef float Float2 __attribute__((ext_vector_type(2)));
+typedef const float __attribute__((address_space(4))) ConstFloat;
+struct TriPairRegs {
+  Float2 v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, ea, eb;
+};
+__device__ __forceinline__ TriPairRegs loadTriPairScalar(const float *triPacked, uint32_t pair) {
+  ConstFloat *g = (ConstFloat *)(triPacked) + 22 * static_cast<size_t>(pair);
+  TriPairRegs t;
+  t.v0x = (Float2){g[0], g[1]}, t.v0y = (Float2){g[2], g[3]}, t.v0z = (Float2){g[4], g[5]};
+  t.e1x = (Float2){g[6], g[7]}, t.e1y = (Float2){g[8], g[9]}, t.e1z = (Float2){g[10], g[11]};
+  t.e2x = (Float2){g[12], g[13]}, t.e2y = (Float2){g[14], g[15]}, t.e2z = (Float2){g[16], g[17]};
+  t.ea = (Float2){g[18], g[19]}, t.eb = (Float2){g[20], g[21]};
+  return t;
+}
+
+// Scene::intersectTriangles with the fp32 PREFILTER (host/prefilter.h has the argument): two triangles per
+// packed instruction; with U = tVec . pVec, V = d . qVec, D = e1 . pVec and W = D - U - V, a triangle is
+// skipped only if min(U, V, W) < -E and max(U, V, W) > E - two of the three certainly have opposite signs, so
+// one of them certainly has the opposite sign of D and the fp64 test (u < 0 | v < 0 | u + v > 1, Scene.cpp:89)
+// rejects whatever D's sign.  All lanes of a wave look at the same pair; the pair goes to the reference's fp64
+// test (all lanes, in index order: the tie-break of the brute-force loop) when ANY lane could not prove its
+// rejection (a comparison with a NaN counts as "could not").
+__device__ __forceinline__ void prefilteredTriangles(d3 o, d3 d, const float *triPacked, const double *triGeom,
+                                                   uint32_t nsph, uint32_t ntri, HitKey &key) {
+  auto splat = [](double x) { const float f = static_cast<float>(x); return (Float2){f, f}; };
+  auto fma2 = [](Float2 a, Float2 b, Float2 c) { return __builtin_elementwise_fma(a, b, c); };
+  const Float2 ox = splat(o.x), oy = splat(o.y), oz = splat(o.z);
+  const Float2 dx = splat(d.x), dy = splat(d.y), dz = splat(d.z);
+  // |o|_inf, not below the true value after the conversion (the bound's coefficient is scaled by it)
+  const float oMax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ox.x), __builtin_fabsf(oy.x)), __builtin_fabsf(oz.x)) *
+                     (1.0f + 0x1p-22f);
+  const Float2 oInf = (Float2){oMax, oMax};
+  const uint32_t npairs = (ntri + 1) >> 1;
+  TriPairRegs cur = loadTriPairScalar(triPacked, 0);
+  for (uint32_t k = 0; k < npairs; ++k) {
+    const TriPairRegs nxt = loadTriPairScalar(triPacked, k + 1 < npairs ? k + 1 : k);
+    const Float2 tx = ox - cur.v0x, ty = oy - cur.v0y, tz = oz - cur.v0z;
+    const Float2 px = fma2(dy, cur.e2z, -(dz * cur.e2y)); // pVec = d x e2
+    const Float2 py = fma2(dz, cur.e2x, -(dx * cur.e2z));
+    const Float2 pz = fma2(dx, cur.e2y, -(dy * cur.e2x));
+    const Float2 det = fma2(cur.e1z, pz, fma2(cur.e1y, py, cur.e1x * px));
+    const Float2 uN = fma2(tz, pz, fma2(ty, py, tx * px));
+    const Float2 qx = fma2(ty, cur.e1z, -(tz * cur.e1y)); // qVec = tVec x e1
+    const Float2 qy = fma2(tz, cur.e1x, -(tx * cur.e1z));
+    const Float2 qz = fma2(tx, cur.e1y, -(ty * cur.e1x));
+    const Float2 vN = fma2(dz, qz, fma2(dy, qy, dx * qx));
+    const Float2 wN = det - uN - vN;
+    const Float2 E = fma2(oInf, cur.eb, cur.ea);
+    // r = max(min(U, V, W) + E, E - max(U, V, W)) per triangle: rejected for certain exactly when r < 0.  A ray
+    // with a NaN or an infinity in it makes U, V and W all NaN (r NaN: kept) or leaves the fp64 test without a
+    // hit as well (its t is NaN or infinite) - and nothing else can produce one here: the scene's coordinates and
+    // every ray origin are bounded (host/prefilter.h: the mode is refused otherwise), so no fp32 product overflows.
+    const Float2 mn = (Float2){__builtin_fminf(__builtin_fminf(uN.x, vN.x), wN.x), __builtin_fminf(__builtin_fminf(uN.y, vN.y), wN.y)};
+    const Float2 mx = (Float2){__builtin_fmaxf(__builtin_fmaxf(uN.x, vN.x), wN.x), __builtin_fmaxf(__builtin_fmaxf(uN.y, vN.y), wN.y)};
+    const Float2 lo = mn + E, hi = E - mx;
+    const float rA = __builtin_fmaxf(lo.x, hi.x), rB = __builtin_fmaxf(lo.y, hi.y);
+    const bool keepA = !(rA < 0.0f), keepB = !(rB < 0.0f);
+    if (__builtin_amdgcn_ballot_w64(keepA | keepB) != 0) {
+      const uint32_t ia = 2 * k, ib = 2 * k + 1;
+      if (__builtin_amdgcn_ballot_w64(keepA) != 0) {
+        const TriRegs t = loadTriScalar(triGeom, ia);
+        testTriangleUFirst(o, d, mk(t.v[0], t.v[1], t.v[2]), mk(t.v[3], t.v[4], t.v[5]), mk(t.v[6], t.v[7], t.v[8]),
+                           nsph + ia, key.t, key.idx, key.det);
+      }
+      if (ib < ntri && __builtin_amdgcn_ballot_w64(keepB) != 0) {
+        const TriRegs t = loadTriScalar(triGeom, ib);
+        testTriangleUFirst(o, d, mk(t.v[0], t.v[1], t.v[2]), mk(t.v[3], t.v[4], t.v[5]), mk(t.v[6], t.v[7], t.v[8]),
+                           nsph + ib, key.t, key.idx, key.det);
+      }
+    }
+    cur = nxt;
+  }
+}
+
+template <int MODE>
 struct PixCtxT {
+  static constexpr bool BVH = MODE == kPixBvh;
   static constexpr bool kLookAhead = false; // (radiance0: a lane never waits for anybody here)
   static constexpr bool kMasterChain = false;
   static constexpr bool kScalarConsts = true; // (four waves per SIMD at 128 registers: ptw_device.h, sconst())
@@ -49,6 +130,7 @@ struct PixCtxT {
   const double *bvhLeafGeom;
   const uint32_t *bvhLeafIndex;
   int32_t *bvhStack; // this lane's slice of the block's LDS traversal stack, stride = blockDim.x
+  const float *triPacked; // prefilter mode only: [(ntri + 1) / 2][22] floats (host/prefilter.h)
   __device__ __forceinline__ Surface surfaceAt(const HitKey &k, d3 o, d3 d, bool = true) const {
     return makeSurface(*p, triShade, spheres, k, o, d);
   }
@@ -209,6 +291,10 @@ struct PixCtxT {
       if (ntri) intersectBvh(o, d, key);
       return key;
     }
+    if (MODE == kPixPrefilter) {
+      if (ntri) prefilteredTriangles(o, d, triPacked, triGeom, nsph, ntri, key);
+      return key;
+    }
     // Scalar loads, one triangle ahead: the nine doubles of a triangle arrive in SGPRs, and every
     // instruction of the test takes at most one of them - no vector loads, no copies, nothing for
     // the other waves of the SIMD to hide (measured against vector loads issued per iteration:
@@ -225,7 +311,7 @@ struct PixCtxT {
   }
 };
 
-using PixCtx = PixCtxT<false>;
+using PixCtx = PixCtxT<kPixBrute>;
 
 constexpr int kPixBlock = 256;
 // resident waves per SIMD the lock-step PERPIXEL kernel is compiled for (A/B: -DPTW_PIX_WAVES=n)
@@ -251,8 +337,8 @@ constexpr int kPixBlock = 256;
 // form left the tree in round 5, last revision 916a1dc): 10 spilled registers instead of 80, 67 instead of
 // 548 B of HBM traffic per sample (24 are the algorithmic ones), Cornell 240.5 against 243.0,
 // suzanne 21.0 against 21.6, single-sphere 313 against 304 Msamples/s.
-template <bool BVH>
-__device__ __forceinline__ d3 radiance0Pix(PixCtxT<BVH> &ctx, const TraceParams &p, const TriShade *triShade,
+template <int MODE>
+__device__ __forceinline__ d3 radiance0Pix(PixCtxT<MODE> &ctx, const TraceParams &p, const TriShade *triShade,
                                            const SphereRec *spheres, d3 o, d3 d) {
   if (p.maxDepth <= 0) return mk(0, 0, 0);
   HitKey k = ctx.intersect(o, d);
@@ -284,7 +370,7 @@ __device__ __forceinline__ d3 radiance0Pix(PixCtxT<BVH> &ctx, const TraceParams 
   return result * p.invFirstBounce; // Vec3::operator/(double): multiply by 1.0 / (nU * nV)
 }
 
-template <bool BVH>
+template <int MODE>
 __device__ __forceinline__ void perPixelSample(const TraceParams &p, const TraceBuffers &b, uint32_t *ldsWords) {
   const uint64_t total = static_cast<uint64_t>(p.npass) * p.pixCount;
   // intersect() calls of all of this lane's samples: ONE atomic per wave at the end (the address is
@@ -301,7 +387,7 @@ __device__ __forceinline__ void perPixelSample(const TraceParams &p, const Trace
   const uint32_t i = static_cast<uint32_t>(gid % p.pixCount);
   const uint32_t pix = globalPixel(p, p.pixBegin + i);
 
-  PixCtxT<BVH> ctx;
+  PixCtxT<MODE> ctx;
   ctx.p = &p;
   ctx.triGeom = b.triGeom;
   ctx.triShade = b.triShade;
@@ -309,6 +395,7 @@ __device__ __forceinline__ void perPixelSample(const TraceParams &p, const Trace
   ctx.bvhNodes = reinterpret_cast<const BvhNodeDev *>(b.bvhNodes);
   ctx.bvhLeafGeom = b.bvhLeafGeom;
   ctx.bvhLeafIndex = b.bvhLeafIndex;
+  ctx.triPacked = b.triPacked;
   const int levels = p.maxDepth > 1 ? p.maxDepth - 1 : 1;
   ctx.bvhStack = reinterpret_cast<int32_t *>(ldsWords + static_cast<size_t>(levels) * blockDim.x) + threadIdx.x;
   ctx.words = 0;

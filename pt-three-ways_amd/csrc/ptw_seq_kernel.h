@@ -275,6 +275,7 @@ hipError_t launchSeq(const TraceParams &pIn, const TraceBuffers &b, const Launch
                                        : traceSequential<SLOTS, WAVES, LDS_TABLES, REG, MASTERS, true>;
   setVariant("traceSequential<%d,%d,%s,%s%s>", SLOTS, WAVES, LDS_TABLES ? "lds" : "global", REG ? "reg" : "stack",
              MASTERS == 2 ? ",2 masters" : "");
+  if (hints.dryRun) return hipSuccess;
   const size_t lds = seqLdsBytes(WAVES, p.maxDepth, LDS_TABLES, p.ntri, p.nmat, p.nsph, MASTERS);
   if (lds > 48 * 1024) { // per launch: the attribute belongs to the current device's copy of the kernel
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),

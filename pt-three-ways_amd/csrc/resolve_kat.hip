@@ -25,14 +25,16 @@ __global__ __launch_bounds__(256) void resolveKernel(const TraceParams p,
 // -----------------------------------------------------------------------------------------
 // Batch Scene::intersect for known-answer tests: one lane per ray.
 // -----------------------------------------------------------------------------------------
+template <int MODE> // kPixBrute, or kPixPrefilter: the same search through the fp32 prefilter (tests)
 __global__ __launch_bounds__(256) void intersectBatchKernel(
     const TraceParams p, const double *__restrict__ triGeom,
     const TriShade *__restrict__ triShade, const SphereRec *__restrict__ spheres,
-    const double *__restrict__ rays, uint64_t n, double *__restrict__ hits) {
+    const double *__restrict__ rays, uint64_t n, double *__restrict__ hits, const float *__restrict__ triPacked) {
   const uint64_t gid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (gid >= n) return;
-  PixCtx ctx;
+  PixCtxT<MODE> ctx;
   ctx.p = &p;
+  ctx.triPacked = triPacked;
   ctx.triGeom = triGeom;
   ctx.triShade = triShade;
   ctx.spheres = spheres;
@@ -114,8 +116,9 @@ hipError_t launchRngKat(int rngPolicy, const uint32_t *mtSeedState, uint32_t see
 hipError_t launchIntersectBatch(const TraceParams &p, const TraceBuffers &b, const double *rays,
                                 uint64_t n, double *hitsOut, hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(intersectBatchKernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256),
-                     0, stream, p, b.triGeom, b.triShade, b.spheres, rays, n, hitsOut);
+  auto kernel = p.accel == PTW_ACCEL_PREFILTER ? intersectBatchKernel<kPixPrefilter> : intersectBatchKernel<kPixBrute>;
+  hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, stream, p, b.triGeom,
+                     b.triShade, b.spheres, rays, n, hitsOut, b.triPacked);
   return hipGetLastError();
 }
 

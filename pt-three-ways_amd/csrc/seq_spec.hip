@@ -537,6 +537,7 @@ hipError_t launchSeqSpec(const TraceParams &p, const TraceBuffers &b, const Laun
   // (LaunchHints::seqSmallKernel == 3: round 5's form, without the next pixel's primary ray traced ahead)
   const bool ahead = hints.seqSmallKernel != 3;
   setVariant(ahead ? "traceSequentialSpec" : "traceSequentialSpec<no cross-pixel candidate>");
+  if (hints.dryRun) return hipSuccess;
   const size_t lds = specLdsBytes(p.ntri, p.nmat, p.nsph);
   auto kernel = b.picks ? (ahead ? traceSequentialSpec<true, true> : traceSequentialSpec<true, false>)
                         : (ahead ? traceSequentialSpec<false, true> : traceSequentialSpec<false, false>);

@@ -62,7 +62,9 @@ void printHelp() {
                "  --gpus <n>                 shard the passes over devices <device> .. <device>+n-1 (1)\n"
                "  --rng <policy>             sequential (reference-exact, default) | perpixel\n"
                "  --accel <mode>             none (the reference's brute force, default) | bvh (perpixel only:\n"
-               "                             same image, triangles culled by a bounding-volume hierarchy)\n"
+               "                             same image, triangles culled by a bounding-volume hierarchy) |\n"
+               "                             prefilter (perpixel only: same image, every triangle looked at in\n"
+               "                             fp32 first and in fp64 only where fp32 cannot prove a miss)\n"
                "  --pix-kernel <kernel>      perpixel policy: auto (default) | lockstep | persistent\n"
                "  --scenes-dir <dir>         where the .obj/.mtl files live (scenes)\n"
                "  --debug <name=value,...>   tests / A-B runs only: ptw_debug_options fields (include/ptw.h),\n"
@@ -146,6 +148,7 @@ Options parse(int argc, const char *argv[]) {
       const std::string m = value(i, a);
       if (m == "none") o.params.accel = PTW_ACCEL_NONE;
       else if (m == "bvh") o.params.accel = PTW_ACCEL_BVH;
+      else if (m == "prefilter") o.params.accel = PTW_ACCEL_PREFILTER;
       else usageError("Unknown accel mode " + m);
     } else if (a == "--pix-kernel") {
       const std::string m = value(i, a);

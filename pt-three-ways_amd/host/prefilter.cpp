@@ -16,8 +16,17 @@ float roundedUp(double x) {
 
 } // namespace
 
-PrefilterData buildPrefilter(const double *triGeom, uint32_t ntri) {
+bool prefilterAcceptsOrigin(const double centre[3], double apertureRadius) {
+  for (int c = 0; c < 3; ++c)
+    if (!std::isfinite(centre[c]) || std::fabs(centre[c]) + std::fabs(apertureRadius) > kPrefilterMaxCoordinate) return false;
+  return std::isfinite(apertureRadius);
+}
+
+PrefilterData buildPrefilter(const double *triGeom, uint32_t ntri, const double *sphCentreRadius, uint32_t nsph) {
   PrefilterData out;
+  for (uint32_t i = 0; i < nsph; ++i) // rays start on sphere surfaces too
+    if (!prefilterAcceptsOrigin(sphCentreRadius + 4 * static_cast<size_t>(i), sphCentreRadius[4 * static_cast<size_t>(i) + 3]))
+      out.usable = false;
   const uint32_t npairs = (ntri + 1) / 2;
   out.pairs.assign(static_cast<size_t>(std::max<uint32_t>(npairs, 1)) * kPrefilterFloatsPerPair, 0.0f);
   for (uint32_t k = 0; k < npairs; ++k) {

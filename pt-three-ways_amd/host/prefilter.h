@@ -33,10 +33,16 @@ constexpr double kPrefilterMaxCoordinate = 1e12; // beyond this fp32 products co
 
 struct PrefilterData {
   std::vector<float> pairs; // [(ntri + 1) / 2][kPrefilterFloatsPerPair]; an odd scene's last B half repeats A
-  bool usable = true;       // false: a coordinate is not finite or beyond kPrefilterMaxCoordinate
+  // false: a triangle coordinate, or a point a ray can start from - a sphere's surface (|centre| + radius) -, is
+  // not finite or beyond kPrefilterMaxCoordinate.  (The third place rays start from, the camera, is checked per
+  // render: prefilterAcceptsOrigin.)  With everything bounded no fp32 product of the prefilter overflows, so its
+  // U, V, W are NaN only for a ray that has a NaN in it - which the fp64 test does not hit anything with either.
+  bool usable = true;
 };
 
-// triGeom: [ntri][9] = v0, e1, e2 (precomputeScene's layout)
-PrefilterData buildPrefilter(const double *triGeom, uint32_t ntri);
+// triGeom: [ntri][9] = v0, e1, e2 (precomputeScene's layout); sphCentreRadius: [nsph][4]
+PrefilterData buildPrefilter(const double *triGeom, uint32_t ntri, const double *sphCentreRadius, uint32_t nsph);
+// a camera centre (+ its aperture radius) the mode can take
+bool prefilterAcceptsOrigin(const double centre[3], double apertureRadius);
 
 } // namespace ptw

@@ -9,9 +9,10 @@ def run(name, w, h, spp, policy, debug):
     scene = pkg.Scene(); cam = scene.build_named(name, w, h)
     ctx = pkg.Context(0); ctx.set_scene(scene); ctx.enable_stats(True)
     extra = {}
-    if "pix_kernel" in debug:   # (a ptw_render_params field, not a debug option: 1 lock-step, 2 persistent)
-        debug = dict(debug)
-        extra["pix_kernel"] = debug.pop("pix_kernel")
+    debug = dict(debug)
+    for field in ("pix_kernel", "accel"):   # (ptw_render_params fields, not debug options: pix_kernel 1 lock-step, 2
+        if field in debug:                  # persistent; accel 1 BVH, 2 fp32 prefilter)
+            extra[field] = debug.pop(field)
     if debug:
         ctx.set_debug(**debug)
     params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=1, rng_policy=policy, **extra)

@@ -163,12 +163,14 @@ def _big_camera(pkg, w, h):
     return pkg.set_focus(pkg.look_at((1, -0.45, 4), (1, -0.6, 0.4), (0, 1, 0), w, h, 40.0), (1, -0.6, 0.4), 0.01)
 
 
-@pytest.mark.parametrize("mode", ["sequential", "sequential-two-masters", "perpixel-lockstep", "perpixel-persistent", "bvh"])
+@pytest.mark.parametrize("mode", ["sequential", "sequential-two-masters", "perpixel-lockstep", "perpixel-persistent", "bvh",
+                                  "prefilter", "prefilter-lockstep"])
 def test_obj_scene_of_24k_triangles_matches_oracle(pkg, ob, big_scene, mode):
     """24 202 triangles through the OBJ / MTL text loader, 8 x 8 x 3 spp.  SEQUENTIAL: the worker waves hold
     12 x 7 x 64 = 5 376 (one master) or 11 x 6 x 64 = 4 224 (two masters) triangles in registers - the other
     19-20 thousand are the streamed tail; radiance, every sample's RNG word count and pick checksum.  PERPIXEL
-    (both kernels) and the BVH mode: radiance and word counts against the oracle under the same policy."""
+    (both kernels), the BVH mode and the fp32 prefilter (both forms): radiance and word counts against the oracle
+    under the same policy."""
     import test_gpu_round3 as r3
     w = h = 8
     cam = _big_camera(pkg, w, h)
@@ -185,12 +187,128 @@ def test_obj_scene_of_24k_triangles_matches_oracle(pkg, ob, big_scene, mode):
         extra = {}
         if mode == "bvh":
             extra["accel"] = pkg.ACCEL_BVH
+        elif mode.startswith("prefilter"):
+            extra["accel"] = pkg.ACCEL_PREFILTER
+            extra["pix_kernel"] = pkg.PIX_KERNEL_LOCKSTEP if mode.endswith("lockstep") else pkg.PIX_KERNEL_AUTO
         else:
             extra["pix_kernel"] = pkg.PIX_KERNEL_LOCKSTEP if mode.endswith("lockstep") else pkg.PIX_KERNEL_PERSISTENT
         params = pkg.default_params(width=w, height=h, samples_per_pixel=3, seed=1, rng_policy=pkg.RNG_PERPIXEL, **extra)
         ref_rgb, ref_cnt, ref_words, _ = ob.oracle_render(big_scene.view(), cam, params, threads=3)
         rgb, cnt, words, kernel, _ = r3._render_with_stats(pkg, big_scene, cam, params)
-        want = {"bvh": "tracePerPixelBvh", "perpixel-lockstep": "tracePerPixel", "perpixel-persistent": "tracePerPixelPersistent"}[mode]
+        want = {"bvh": "tracePerPixelBvh", "perpixel-lockstep": "tracePerPixel", "perpixel-persistent": "tracePerPixelPersistent",
+                "prefilter": "tracePerPixelPersistentPrefilter", "prefilter-lockstep": "tracePerPixelPrefilter"}[mode]
         assert kernel == want, kernel
     assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words)
     assert rel_err(rgb, ref_rgb) < TOL
+
+
+# ---- the one-master and single-wave instantiations, by name ------------------------------------------------------
+# (tests/test_dispatch_plan.py lists what the dispatcher can produce; every name must be held to the oracle somewhere)
+ONE_MASTER_CASES = [
+    (100, "lds", "traceSequential<2,1,lds,stack>"),
+    (100, "global", "traceSequential<2,1,global,stack>"),
+    (200, "lds", "traceSequential<1,7,lds,stack>"),
+    (200, "global", "traceSequential<1,7,global,stack>"),
+    (500, "lds", "traceSequential<2,7,lds,stack>"),
+    (500, "global", "traceSequential<2,7,global,stack>"),
+    (1000, "lds", "traceSequential<3,7,lds,stack>"),
+    (1000, "global", "traceSequential<3,7,global,stack>"),
+    (1350, "lds", "traceSequential<4,7,lds,stack>"),
+    (1700, "global", "traceSequential<4,7,global,stack>"),
+    (2500, "global", "traceSequential<6,7,global,stack>"),
+    (3400, "global", "traceSequential<8,7,global,stack>"),
+    (5600, "global", "traceSequential<12,7,global,stack>"),    # beyond 12 x 7 x 64 = 5 376 resident: a streamed tail
+]
+
+
+@pytest.mark.parametrize("ntri,tables,kernel", ONE_MASTER_CASES)
+def test_one_master_and_single_wave_kernels_match_oracle(pkg, ob, monkeypatch, ntri, tables, kernel):
+    """Every <SLOTS, 7> (seven worker waves, one master) and <2, 1> (one wave, two triangles per lane)
+    instantiation the dispatcher can pick, against the oracle on a triangle soup: radiance, every sample's RNG
+    word count and pick checksum - in one band, and with a staging budget that parks every pass's stream."""
+    import test_gpu_round3 as r3
+    assert pkg.dispatch_plan(ntri, num_spheres=3, num_materials=5, samples_per_pixel=3, seq_two_masters=0,
+                             **({"seq_lds_tables": 0} if tables == "global" and ntri < 1400 else {})) == kernel
+    for spp, budget_kb in ((3, None), (2, 1)):
+        monkeypatch.delenv("PTW_STAGE_BUDGET_KB", raising=False)
+        if budget_kb:
+            monkeypatch.setenv("PTW_STAGE_BUDGET_KB", str(budget_kb))
+        debug = dict(seq_two_masters=0)
+        if tables == "global" and ntri < 1400:
+            debug["seq_lds_tables"] = 0
+        w, h = (12, 10) if budget_kb else (4, 3)
+        scene, cam = r3._soup(pkg, ntri, 2, seed=17 * ntri + spp, w=w, h=h)
+        params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=6)
+        ref_rgb, ref_cnt, ref_words, ref_picks = ob.oracle_render_picks(scene.view(), cam, params, threads=3)
+        rgb, cnt, words, variant, launches, picks = r3._render_with_stats(pkg, scene, cam, params, picks=True, **debug)
+        assert variant == kernel, variant
+        assert not budget_kb or launches > 1
+        assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words)
+        assert np.array_equal(picks, ref_picks), "a ray hit another primitive than in the oracle"
+        assert rel_err(rgb, ref_rgb) < TOL
+
+
+def test_first_contact_kit_dry_run_on_one_gpu():
+    """scripts/first_contact_8gpu.sh - the script to run FIRST on a real multi-GPU node (no scaling curve was ever
+    measured: no such node was available) - dry-run here with two ranks sharing the one GPU: the single-process
+    communicator set-up + describe + reduce (loopback transport), `bench.py --gpus 1,2` under both policies with
+    the image comparison (RCCL's socket transport), the CLI's `--gpus 2`."""
+    import os
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="VERSION", PTW_COLLECTIVE_TIMEOUT_S="120")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NCCL_DEBUG_FILE"):
+        env.pop(k, None)
+    proc = subprocess.run(["bash", str(ROOT / "scripts" / "first_contact_8gpu.sh"), "--gpus", "1,2", "--share"], capture_output=True,
+                          text=True, timeout=900, env=env, cwd=ROOT)
+    if proc.returncode != 0 and "Duplicate GPU detected" in proc.stdout + proc.stderr:
+        pytest.skip("RCCL refused two ranks on one GPU despite NCCL_HOSTID")
+    assert proc.returncode == 0 and "FIRST CONTACT OK" in proc.stdout, proc.stdout[-3000:] + proc.stderr[-2000:]
+    assert "reduce over 2 communicators: root holds 3 everywhere" in proc.stdout
+
+
+# ---- what round 6's dispatch sweep exposed -----------------------------------------------------------------------
+@pytest.mark.parametrize("ntri", [32, 64])
+def test_small_scene_kernels_with_more_passes_than_cus_match_oracle(pkg, ob, ntri):
+    """Scenes of at most 64 triangles at 300 passes on 256 CUs - the range where the dispatcher's static rule
+    (`one wave per pass beyond one pass per CU`) lost 1.7x on closed scenes in the sweep (profiles/r06*_dispatch_sweep.md):
+    each of the two kernels forced, and the dispatcher after ptw_context_calibrate, against the oracle - radiance,
+    every sample's RNG word count and pick checksum; the three images agree with each other to 1e-13."""
+    import torch
+    import test_gpu_round3 as r3
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    spp = cus + 44
+    w = h = 16
+    scene, cam = r3._soup(pkg, ntri, 2, seed=ntri, w=w, h=h)
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=1)
+    ref_rgb, ref_cnt, ref_words, ref_picks = ob.oracle_render_picks(scene.view(), cam, params, threads=8)
+    images = {}
+    for name, debug in (("traceSequentialSpec", dict(seq_small_kernel=2)), ("traceSequential<1,1,lds,reg>", dict(seq_small_kernel=1))):
+        rgb, cnt, words, variant, _, picks = r3._render_with_stats(pkg, scene, cam, params, picks=True, **debug)
+        assert variant == name, variant
+        assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words) and np.array_equal(picks, ref_picks), name
+        assert rel_err(rgb, ref_rgb) < TOL
+        images[name] = rgb
+    # the dispatcher on its own: the static rule says one wave per pass ...
+    rgb, cnt, words, variant, _ = r3._render_with_stats(pkg, scene, cam, params)
+    assert variant == "traceSequential<1,1,lds,reg>", variant
+    # ... and after the timed trial the kernel that measured faster - on a closed scene the speculative one
+    ctx = pkg.Context(0)
+    ctx.set_scene(scene)
+    ctx.enable_stats(True)
+    st = torch.cuda.current_stream().cuda_stream
+    assert ctx.calibrate(cam, params, st) == pkg.PIX_KERNEL_AUTO
+    rgb_t = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+    cnt_t = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    words_t = torch.zeros((spp, h, w), dtype=torch.int32, device="cuda")
+    ctx.render(cam, params, rgb_t.data_ptr(), cnt_t.data_ptr(), words_t.data_ptr(), st)
+    torch.cuda.synchronize()
+    chosen = ctx.stats(reset=True).trace_kernel.decode()
+    assert chosen == "traceSequentialSpec", chosen
+    assert np.array_equal(words_t.cpu().numpy().astype(np.uint32), ref_words) and rel_err(rgb_t.cpu().numpy(), ref_rgb) < TOL
+    # another pass count: the measurement does not carry over
+    p2 = pkg.default_params(width=w, height=h, samples_per_pixel=spp + 1, seed=1)
+    ctx.render(cam, p2, rgb_t.data_ptr(), cnt_t.data_ptr(), 0, st)
+    torch.cuda.synchronize()
+    assert ctx.stats(reset=True).trace_kernel.decode() == "traceSequential<1,1,lds,reg>"
+    a, b = images.values()
+    assert float(np.max(np.abs(a - b) / np.maximum(np.abs(a), 1.0))) < 1e-13
