@@ -261,7 +261,7 @@ class Shard:
             self.parallelism = "single GPU"
         self.rows = args.height
         if args.accel != "none":
-            assert self.policy == pkg.RNG_PERPIXEL, "--accel needs --policy perpixel"
+            assert self.policy == pkg.RNG_PERPIXEL or args.accel == "prefilter", "--accel bvh needs --policy perpixel"
             extra = dict(extra, accel=pkg.ACCEL_BVH if args.accel == "bvh" else pkg.ACCEL_PREFILTER)
         if args.rows:
             assert world == 1, "--rows times a sub-run on one GPU"
@@ -453,7 +453,7 @@ def parity_vs_reference(pkg, ob, ctx, cam, view, scene_name, w, h, total_spp, se
 # Bounded parity windows of the side configurations (rows of the frame x passes): about 10-25 s of
 # host work each on six cores.  `--parity-rows` / `--parity-passes` widen them (`--config cfg3
 # --parity-rows 1024 --parity-passes 2`: one whole-frame comparison, kept under profiles/).
-SIDE_PARITY = {"cfg3": dict(rows_end=64, passes=6), "cfg4": dict(rows_end=4, passes=6)}
+SIDE_PARITY = {"cfg3": dict(rows_end=256, passes=2), "cfg4": dict(rows_end=4, passes=6)}   # (r6: cfg3 a quarter of the frame)
 
 
 def roofline_of(stats, ntri, nsph):
@@ -515,6 +515,26 @@ def side_config(pkg, ob, name, device, threads, want_parity, want_cpu=False, cpu
         "kernel": roof["kernel"], "frac": roof["frac"], "achieved_tflops": roof["achieved"],
         "avg_launch_ms": roof["avg_launch_ms"], "launches": roof["launches"], "rays_per_sample": roof["rays_per_sample"],
     }
+    # the SEPARATE mode beside it (never the configuration's number): the same render with the fp32 prefilter in the
+    # worker lanes (PTW_ACCEL_PREFILTER under the sequential policy) - and whether it wrote the same bytes
+    if view.num_triangles > 128:
+        rgb2 = torch.zeros_like(rgb)
+        cnt2 = torch.zeros_like(cnt)
+        p2 = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=1, rng_policy=pkg.RNG_SEQUENTIAL,
+                                device=device, accel=pkg.ACCEL_PREFILTER, **extra)
+        ctx.enable_stats(True)
+        ctx.stats(reset=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.render(cam, p2, rgb2.data_ptr(), cnt2.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        st2 = ctx.stats(reset=True)
+        ctx.enable_stats(False)
+        out["prefilter_mode"] = {"value": w * rows * spp / dt2 / 1e6, "kernel": st2.trace_kernel.decode(),
+                                 "same_bytes": bool(torch.equal(rgb, rgb2) and torch.equal(cnt, cnt2)),
+                                 "note": "separate mode: fp32 look before the fp64 test, same image"}
+        del rgb2, cnt2
     if want_parity:
         par, leg = parity_vs_reference(pkg, ob, ctx, cam, view, cfg["scene"], w, h, spp, 1,
                                        SIDE_PARITY[name]["passes"], SIDE_PARITY[name]["rows_end"], threads,
@@ -528,6 +548,39 @@ def side_config(pkg, ob, name, device, threads, want_parity, want_cpu=False, cpu
         # the frame size): 6 threads x 2 passes each, as scripts/bench-6t-*.sh run the reference
         out["cpu_baseline"] = cpu_leg(pkg, ob, cfg["scene"], cpu_threads, 2 * cpu_threads, CPU_SAMPLE_FRAME[cfg["scene"]])
         out["vs_cpu_6t"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
+def accel_leg(pkg, device):
+    """The SEPARATE accelerated modes of SURVEY 8 f4 (PERPIXEL policy; never the headline): the brute-force
+    kernel, the conservative fp32 prefilter (every triangle still looked at) and the BVH on the
+    two large scenes, one timed render each, and whether the three images are the same BYTES."""
+    out = {"note": "separate modes, perpixel policy, never the headline; Msamples/s"}
+    for name, edge, spp in (("suzanne", 1024, 16), ("ce", 512, 16)):
+        scene = pkg.Scene()
+        cam = scene.build_named(name, edge, edge)
+        ctx = pkg.Context(device)
+        ctx.set_scene(scene)
+        stream = torch.cuda.current_stream().cuda_stream
+        row, images = {}, []
+        for label, accel in (("brute", pkg.ACCEL_NONE), ("prefilter", pkg.ACCEL_PREFILTER), ("bvh", pkg.ACCEL_BVH)):
+            params = pkg.default_params(width=edge, height=edge, samples_per_pixel=spp, seed=1, rng_policy=pkg.RNG_PERPIXEL,
+                                        device=device, accel=accel)
+            rgb = torch.zeros((edge, edge, 3), dtype=torch.float64, device="cuda")
+            cnt = torch.zeros((edge, edge), dtype=torch.int32, device="cuda")
+            warm = pkg.default_params(width=edge, height=edge, samples_per_pixel=spp, seed=1, rng_policy=pkg.RNG_PERPIXEL,
+                                      device=device, accel=accel, row_begin=0, row_end=1)
+            ctx.render(cam, warm, rgb.data_ptr(), cnt.data_ptr(), 0, stream)
+            torch.cuda.synchronize()
+            rgb.zero_()
+            cnt.zero_()
+            t0 = time.perf_counter()
+            ctx.render(cam, params, rgb.data_ptr(), cnt.data_ptr(), 0, stream)
+            torch.cuda.synchronize()
+            row[label] = round(edge * edge * spp / (time.perf_counter() - t0) / 1e6, 3)
+            images.append(rgb)
+        row["same_bytes"] = bool(torch.equal(images[0], images[1]) and torch.equal(images[0], images[2]))
+        out[f"{name}_{edge}x{edge}x{spp}"] = row
     return out
 
 
@@ -861,6 +914,8 @@ def main():
                                 args.cpu_threads) if in_time() else
                     {"config": name, "value": None, "note": f"skipped after {SIDE_LEG_DEADLINE_S} s; run --config {name}"}
                     for name in ("cfg3", "cfg4")]
+            if not args.no_other_configs and in_time():
+                result["accel_modes"] = accel_leg(pkg, device)
             if not args.no_strict:
                 result["strict_fp"] = strict_leg(args) if in_time() else \
                     {"value": None, "note": f"skipped after {SIDE_LEG_DEADLINE_S} s"}

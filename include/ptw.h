@@ -64,7 +64,9 @@ typedef enum ptw_rng_policy { PTW_RNG_SEQUENTIAL = 0, PTW_RNG_PERPIXEL = 1 } ptw
  *         every triangle (src/dod/Scene.cpp:62-98), but first in fp32 - two triangles per packed
  *         instruction - and the reference's fp64 test runs only where the fp32 evaluation, with a
  *         stated forward error bound, cannot PROVE that the fp64 test rejects.  Bit-identical samples
- *         (a plain fp32 test would flip decisions); PTW_RNG_PERPIXEL only; refused with
+ *         (a plain fp32 test would flip decisions).  Under PTW_RNG_PERPIXEL both kernel forms; under
+ *         PTW_RNG_SEQUENTIAL the worker-wave kernels (scenes beyond 128 triangles: the worker lanes hold
+ *         their triangles in fp32 and fetch the fp64 data of the few survivors).  Refused with
  *         PTW_ERR_UNSUPPORTED for scenes with coordinates beyond 1e12 (fp32 products could overflow). */
 typedef enum ptw_accel { PTW_ACCEL_NONE = 0, PTW_ACCEL_BVH = 1, PTW_ACCEL_PREFILTER = 2 } ptw_accel;
 

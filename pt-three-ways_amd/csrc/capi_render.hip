@@ -193,10 +193,10 @@ void validate(const ptw_render_params &p) {
   if (p.pix_kernel != PTW_PIX_KERNEL_AUTO && p.pix_kernel != PTW_PIX_KERNEL_LOCKSTEP &&
       p.pix_kernel != PTW_PIX_KERNEL_PERSISTENT)
     throw std::invalid_argument("unknown pix_kernel");
-  if (p.accel != PTW_ACCEL_NONE && p.rng_policy != PTW_RNG_PERPIXEL)
+  if (p.accel == PTW_ACCEL_BVH && p.rng_policy != PTW_RNG_PERPIXEL)
     throw DeviceError(PTW_ERR_UNSUPPORTED,
-                      "the accelerated mode needs PTW_RNG_PERPIXEL (the SEQUENTIAL kernels search the "
-                      "scene cooperatively, a lane per primitive)");
+                      "PTW_ACCEL_BVH needs PTW_RNG_PERPIXEL (the SEQUENTIAL kernels search the scene cooperatively, a lane "
+                      "per primitive: there is no ray to walk a hierarchy with)");
 
   // Under PTW_RNG_SEQUENTIAL the pixels of a pass share one stream, consumed in row-major order: the
   // only window that means anything is a PREFIX of the frame (rows [0, row_end): exactly what the
@@ -405,6 +405,10 @@ void enqueueRender(ptw_context &ctx, const ptw_camera &cam, const ptw_render_par
   if (calibrate) *calibrate = kPixKernelAuto;
   validate(p);
   if (!ctx.haveScene) throw std::invalid_argument("no scene set on this context");
+  if (p.accel == PTW_ACCEL_PREFILTER && p.rng_policy == PTW_RNG_SEQUENTIAL && ctx.ntri <= 128)
+    throw DeviceError(PTW_ERR_UNSUPPORTED,
+                      "PTW_ACCEL_PREFILTER under PTW_RNG_SEQUENTIAL is a form of the worker-wave kernels: scenes beyond 128 "
+                      "triangles (a smaller scene's search is a handful of instructions per lane)");
   if (p.accel == PTW_ACCEL_PREFILTER && !(ctx.prefilterUsable && prefilterAcceptsOrigin(cam.centre, cam.aperture_radius)))
     throw DeviceError(PTW_ERR_UNSUPPORTED,
                       "PTW_ACCEL_PREFILTER: the scene (or the camera) has coordinates that are not finite or beyond 1e12 - "
@@ -682,8 +686,10 @@ int ptw_dispatch_plan(const ptw_dispatch_query *q, const ptw_debug_options *debu
   if (!q || !out || capacity == 0) return invalid("null pointer");
   PTW_GUARD_BEGIN
   if (q->rng_policy != PTW_RNG_SEQUENTIAL && q->rng_policy != PTW_RNG_PERPIXEL) throw std::invalid_argument("unknown rng_policy");
-  if (q->accel != PTW_ACCEL_NONE && q->rng_policy != PTW_RNG_PERPIXEL)
-    throw DeviceError(PTW_ERR_UNSUPPORTED, "the accelerated modes need PTW_RNG_PERPIXEL");
+  if (q->accel == PTW_ACCEL_BVH && q->rng_policy != PTW_RNG_PERPIXEL)
+    throw DeviceError(PTW_ERR_UNSUPPORTED, "PTW_ACCEL_BVH needs PTW_RNG_PERPIXEL");
+  if (q->accel == PTW_ACCEL_PREFILTER && q->rng_policy == PTW_RNG_SEQUENTIAL && q->num_triangles <= 128)
+    throw DeviceError(PTW_ERR_UNSUPPORTED, "PTW_ACCEL_PREFILTER under PTW_RNG_SEQUENTIAL: scenes beyond 128 triangles");
   if (q->samples_per_pixel <= 0) throw std::invalid_argument("samples_per_pixel must be positive");
   ptw_context probe; // (never touches a device: only its debug -> hints translation is used)
   if (debug) probe.debug = *debug;

@@ -84,6 +84,8 @@ hipError_t dispatchSequential(const TraceParams &p, const TraceBuffers &b, const
   // LaunchHints::seqTwoMasters 0 / 1: never / always.
   const bool mm = hints.seqTwoMasters == 0 || hints.seqTwoMasters == 1 ? hints.seqTwoMasters == 1
                                                                       : p.npass > static_cast<uint32_t>(cusFor(hints));
+  if (p.accel == PTW_ACCEL_PREFILTER) // (the separate mode: the worker lanes look in fp32 first)
+    return mm ? launchSeqTwoMastersPrefilter(p, b, hints, stream) : launchSeqOneMasterPrefilter(p, b, hints, stream);
   return mm ? launchSeqTwoMasters(p, b, hints, stream) : launchSeqOneMaster(p, b, hints, stream);
 }
 } // namespace

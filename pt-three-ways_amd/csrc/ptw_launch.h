@@ -8,6 +8,7 @@
 //   seq_spec.hip      traceSequentialSpec                       four speculating waves per pass (<= 64 triangles)
 //   seq_worker.hip    traceSequential<SLOTS, 7, ...>            seven worker waves + one master
 //   seq_worker2.hip   traceSequential<SLOTS, 6, ..., 2 masters> six worker waves shared by two passes
+//   seq_worker_pre.hip, seq_worker2_pre.hip   the same two families with the fp32 prefilter in the worker lanes
 //   perpixel.hip      tracePerPixel, tracePerPixelPersistent    PERPIXEL policy, brute force
 //   accel.hip         tracePerPixelBvh, tracePerPixelPrefilter  the separate accelerated modes
 //   resolve_kat.hip   resolveKernel, intersectBatchKernel, rngKatKernel
@@ -37,6 +38,10 @@ hipError_t launchSeqSingle(const TraceParams &p, const TraceBuffers &b, const La
                            int slots, bool reg);
 hipError_t launchSeqOneMaster(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream);
 hipError_t launchSeqTwoMasters(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream);
+// ... and the same two families with the fp32 prefilter in the worker lanes (seq_worker_pre.hip, seq_worker2_pre.hip:
+// PTW_ACCEL_PREFILTER under the SEQUENTIAL policy)
+hipError_t launchSeqOneMasterPrefilter(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream);
+hipError_t launchSeqTwoMastersPrefilter(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream);
 
 // ---- PERPIXEL: the accelerated modes (accel.hip; launchTracePerPixel in perpixel.hip hands over) -----------
 hipError_t launchTraceAccel(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream);

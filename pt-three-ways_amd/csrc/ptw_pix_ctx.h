@@ -41,7 +41,6 @@ constexpr int kPixBrute = 0, kPixBvh = 1, kPixPrefilter = 2;
 
 // The fp32 data of two triangles for the prefilter (host/prefilter.h: component-interleaved, then the
 // error-bound coefficients), through scalar loads like the fp64 triangles.
-typedef float Float2 __attribute__((ext_vector_type(2)));
 typedef const float __attribute__((address_space(4))) ConstFloat;
 struct TriPairRegs {
   Float2 v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, ea, eb;
@@ -65,39 +64,15 @@ __device__ __forceinline__ TriPairRegs loadTriPairScalar(const float *triPacked,
 // rejection (a comparison with a NaN counts as "could not").
 __device__ __forceinline__ void prefilteredTriangles(d3 o, d3 d, const float *triPacked, const double *triGeom,
                                                    uint32_t nsph, uint32_t ntri, HitKey &key) {
-  auto splat = [](double x) { const float f = static_cast<float>(x); return (Float2){f, f}; };
-  auto fma2 = [](Float2 a, Float2 b, Float2 c) { return __builtin_elementwise_fma(a, b, c); };
-  const Float2 ox = splat(o.x), oy = splat(o.y), oz = splat(o.z);
-  const Float2 dx = splat(d.x), dy = splat(d.y), dz = splat(d.z);
-  // |o|_inf, not below the true value after the conversion (the bound's coefficient is scaled by it)
-  const float oMax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ox.x), __builtin_fabsf(oy.x)), __builtin_fabsf(oz.x)) *
-                     (1.0f + 0x1p-22f);
-  const Float2 oInf = (Float2){oMax, oMax};
+  const PrefilterRay ray = prefilterRay(o, d);
   const uint32_t npairs = (ntri + 1) >> 1;
   TriPairRegs cur = loadTriPairScalar(triPacked, 0);
   for (uint32_t k = 0; k < npairs; ++k) {
     const TriPairRegs nxt = loadTriPairScalar(triPacked, k + 1 < npairs ? k + 1 : k);
-    const Float2 tx = ox - cur.v0x, ty = oy - cur.v0y, tz = oz - cur.v0z;
-    const Float2 px = fma2(dy, cur.e2z, -(dz * cur.e2y)); // pVec = d x e2
-    const Float2 py = fma2(dz, cur.e2x, -(dx * cur.e2z));
-    const Float2 pz = fma2(dx, cur.e2y, -(dy * cur.e2x));
-    const Float2 det = fma2(cur.e1z, pz, fma2(cur.e1y, py, cur.e1x * px));
-    const Float2 uN = fma2(tz, pz, fma2(ty, py, tx * px));
-    const Float2 qx = fma2(ty, cur.e1z, -(tz * cur.e1y)); // qVec = tVec x e1
-    const Float2 qy = fma2(tz, cur.e1x, -(tx * cur.e1z));
-    const Float2 qz = fma2(tx, cur.e1y, -(ty * cur.e1x));
-    const Float2 vN = fma2(dz, qz, fma2(dy, qy, dx * qx));
-    const Float2 wN = det - uN - vN;
-    const Float2 E = fma2(oInf, cur.eb, cur.ea);
-    // r = max(min(U, V, W) + E, E - max(U, V, W)) per triangle: rejected for certain exactly when r < 0.  A ray
-    // with a NaN or an infinity in it makes U, V and W all NaN (r NaN: kept) or leaves the fp64 test without a
-    // hit as well (its t is NaN or infinite) - and nothing else can produce one here: the scene's coordinates and
-    // every ray origin are bounded (host/prefilter.h: the mode is refused otherwise), so no fp32 product overflows.
-    const Float2 mn = (Float2){__builtin_fminf(__builtin_fminf(uN.x, vN.x), wN.x), __builtin_fminf(__builtin_fminf(uN.y, vN.y), wN.y)};
-    const Float2 mx = (Float2){__builtin_fmaxf(__builtin_fmaxf(uN.x, vN.x), wN.x), __builtin_fmaxf(__builtin_fmaxf(uN.y, vN.y), wN.y)};
-    const Float2 lo = mn + E, hi = E - mx;
-    const float rA = __builtin_fmaxf(lo.x, hi.x), rB = __builtin_fmaxf(lo.y, hi.y);
-    const bool keepA = !(rA < 0.0f), keepB = !(rB < 0.0f);
+    // (a ray with a NaN or an infinity in it makes r NaN - kept - or leaves the fp64 test without a hit as well;
+    // nothing else can produce one: the scene's coordinates and every ray origin are bounded, host/prefilter.h)
+    const Float2 r = prefilterPair(ray, cur.v0x, cur.v0y, cur.v0z, cur.e1x, cur.e1y, cur.e1z, cur.e2x, cur.e2y, cur.e2z, cur.ea, cur.eb);
+    const bool keepA = !(r.x < 0.0f), keepB = !(r.y < 0.0f);
     if (__builtin_amdgcn_ballot_w64(keepA | keepB) != 0) {
       const uint32_t ia = 2 * k, ib = 2 * k + 1;
       if (__builtin_amdgcn_ballot_w64(keepA) != 0) {

@@ -115,8 +115,19 @@ struct SeqTables {
 // Layout of the per-lane shading record of the REG path (doubles).
 constexpr int kRecEmission = 0, kRecDiffuse = 3, kRecDoubles = 6;
 
-template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false, bool SPEC = false, int MASTERS = 1, bool PICKS = true>
+// PRE (worker-wave kernels, PTW_ACCEL_PREFILTER under the SEQUENTIAL policy - a separate, separately reported
+// mode): the worker lanes hold their triangles in fp32 - two slots per register pair - and look at them with the
+// conservative prefilter of host/prefilter.h (two triangles per packed instruction: 38 VALU instructions per PAIR
+// of slots against 50 per slot); the reference's fp64 test runs only for the slots whose rejection fp32 cannot
+// prove, on v0 / e1 / e2 fetched from memory by the lanes that need them.  Same hits, bit for bit.
+template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false, bool SPEC = false, int MASTERS = 1, bool PICKS = true,
+          bool PRE = false>
 struct SeqCtx {
+  static_assert(!PRE || (WAVES > 1 && !REG && !SPEC), "the prefilter form exists for the worker-wave kernels");
+  static constexpr int kPairs = (SLOTS + 1) / 2;
+  Float2 pv0x[kPairs], pv0y[kPairs], pv0z[kPairs], pe1x[kPairs], pe1y[kPairs], pe1z[kPairs], pe2x[kPairs], pe2y[kPairs],
+      pe2z[kPairs], pea[kPairs], peb[kPairs]; // PRE only (never touched otherwise)
+  const float *triPacked;                       // PRE: [(ntri + 1) / 2][22] floats (host/prefilter.h)
   // REG (single wave, one triangle per lane, at most 127 primitives, maxDepth <= 9): every lane
   // also keeps the emission and diffuse colour of its triangle in registers, and the (E, T)
   // stack is one byte per level (combined primitive index + lobe flag) in a scalar register
@@ -237,8 +248,29 @@ struct SeqCtx {
 
   __device__ __forceinline__ void loadPrimitives() {
     const uint32_t ntri = p->ntri;
+    if constexpr (PRE) {
+      // fp32 copies from the pair records (triangle k: record k / 2, half k % 2); a slot without a triangle gets
+      // E = -1: r = max(0 + E, E - 0) < 0 - "rejected for certain" at no extra instruction
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
+      for (int q = 0; q < kPairs; ++q) {
+        float v[2][11];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int s = 2 * q + h;
+          const uint32_t k = slotTriangle(s);
+          const bool valid = s < SLOTS && k < ntri && s < myUnits;
+          const float *rec = triPacked + 22 * static_cast<size_t>(valid ? (k >> 1) : 0u) + (valid ? (k & 1u) : 0u);
+#pragma unroll
+          for (int c = 0; c < 11; ++c) v[h][c] = valid ? rec[2 * c] : (c == 9 ? -1.0f : 0.0f);
+        }
+        pv0x[q] = (Float2){v[0][0], v[1][0]}, pv0y[q] = (Float2){v[0][1], v[1][1]}, pv0z[q] = (Float2){v[0][2], v[1][2]};
+        pe1x[q] = (Float2){v[0][3], v[1][3]}, pe1y[q] = (Float2){v[0][4], v[1][4]}, pe1z[q] = (Float2){v[0][5], v[1][5]};
+        pe2x[q] = (Float2){v[0][6], v[1][6]}, pe2y[q] = (Float2){v[0][7], v[1][7]}, pe2z[q] = (Float2){v[0][8], v[1][8]};
+        pea[q] = (Float2){v[0][9], v[1][9]}, peb[q] = (Float2){v[0][10], v[1][10]};
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < (PRE ? 0 : SLOTS); ++s) {
       // Branch-free on purpose: with an if/else the compiler sinks the two stores into one with a
       // runtime slot index, which sends the slot arrays to scratch memory.  An unused slot gets a
       // degenerate triangle (det == 0 -> always skipped); triGeom holds at least one record.
@@ -469,8 +501,31 @@ struct SeqCtx {
         const SphereRec &r = spheresGlobal[i];
         testSphere(o, d, ld3(r.centre), r.radiusSquared, i, bestT, bestIdx);
       }
+    if constexpr (PRE) {
+      // the fp32 look at every resident slot, two per instruction; bit s of `keep`: slot s goes to the fp64 test
+      const PrefilterRay ray = prefilterRay(o, d);
+      uint32_t keep = 0;
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
+      for (int q = 0; q < kPairs; ++q) {
+        if (2 * q >= myUnits) continue; // (wave-uniform: this wave's share ends at myUnits)
+        const Float2 r = prefilterPair(ray, pv0x[q], pv0y[q], pv0z[q], pe1x[q], pe1y[q], pe1z[q], pe2x[q], pe2y[q], pe2z[q],
+                                       pea[q], peb[q]);
+        keep |= (!(r.x < 0.0f) ? 1u : 0u) << (2 * q) | (!(r.y < 0.0f) ? 2u : 0u) << (2 * q);
+      }
+      // ... and the reference's test for the slots that are left, lowest slot first (a lane's slots are in index
+      // order, `<` is strict: the tie-break of the plain loop), each lane on the triangle it still has to look at
+      while (__builtin_amdgcn_ballot_w64(keep != 0) != 0) {
+        if (keep != 0) {
+          const int s = __builtin_ctz(keep);
+          keep &= keep - 1;
+          const uint32_t k = slotTriangle(s);
+          const double *g = triGeom + 9 * static_cast<size_t>(k);
+          testTriangle(o, d, ld3(g), ld3(g + 3), ld3(g + 6), nsph + k, bestT, bestIdx, bestDet);
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < (PRE ? 0 : SLOTS); ++s) {
       // (wave-uniform: this wave's share of the scene ends at myUnits.  A guard, not a `break`: with a
       // second loop exit the compiler stops unrolling from nine slots on, indexes the slot arrays
       // at run time and moves them to scratch memory)

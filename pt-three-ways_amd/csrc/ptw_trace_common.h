@@ -93,6 +93,51 @@ __device__ __forceinline__ void testTriangleUFirst(d3 o, d3 d, d3 v0, d3 e1, d3 
   }
 }
 
+// Two fp32 values in one 64-bit register pair: the operand type of v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+// (the conservative fp32 prefilter of PTW_ACCEL_PREFILTER: host/prefilter.h).
+typedef float Float2 __attribute__((ext_vector_type(2)));
+
+// The prefilter's look at TWO triangles (the halves of every operand) against one ray: r < 0 in a half = that
+// triangle is rejected for certain.  U = tVec . pVec, V = d . qVec, D = e1 . pVec, W = D - U - V in fp32;
+// r = max(min(U, V, W) + E, E - max(U, V, W)) with E = ea + |o|_inf * eb: negative exactly when two of U, V, W
+// certainly have opposite signs - then one of them certainly has the opposite sign of D and the reference's test
+// (u < 0 | v < 0 | u + v > 1, src/dod/Scene.cpp:89) rejects whatever D's sign.  A NaN r (a ray with a NaN in it)
+// compares false: kept.
+struct PrefilterRay {
+  Float2 ox, oy, oz, dx, dy, dz, oInf;
+};
+__device__ __forceinline__ PrefilterRay prefilterRay(d3 o, d3 d) {
+  auto splat = [](double x) { const float f = static_cast<float>(x); return (Float2){f, f}; };
+  PrefilterRay r;
+  r.ox = splat(o.x), r.oy = splat(o.y), r.oz = splat(o.z);
+  r.dx = splat(d.x), r.dy = splat(d.y), r.dz = splat(d.z);
+  // |o|_inf, not below the true value after the conversion (the bound's coefficient is scaled by it)
+  const float oMax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(r.ox.x), __builtin_fabsf(r.oy.x)), __builtin_fabsf(r.oz.x)) *
+                     (1.0f + 0x1p-22f);
+  r.oInf = (Float2){oMax, oMax};
+  return r;
+}
+__device__ __forceinline__ Float2 prefilterPair(const PrefilterRay &r, Float2 v0x, Float2 v0y, Float2 v0z, Float2 e1x, Float2 e1y,
+                                                Float2 e1z, Float2 e2x, Float2 e2y, Float2 e2z, Float2 ea, Float2 eb) {
+  auto fma2 = [](Float2 a, Float2 b, Float2 c) { return __builtin_elementwise_fma(a, b, c); };
+  const Float2 tx = r.ox - v0x, ty = r.oy - v0y, tz = r.oz - v0z;
+  const Float2 px = fma2(r.dy, e2z, -(r.dz * e2y)); // pVec = d x e2
+  const Float2 py = fma2(r.dz, e2x, -(r.dx * e2z));
+  const Float2 pz = fma2(r.dx, e2y, -(r.dy * e2x));
+  const Float2 det = fma2(e1z, pz, fma2(e1y, py, e1x * px));
+  const Float2 uN = fma2(tz, pz, fma2(ty, py, tx * px));
+  const Float2 qx = fma2(ty, e1z, -(tz * e1y)); // qVec = tVec x e1
+  const Float2 qy = fma2(tz, e1x, -(tx * e1z));
+  const Float2 qz = fma2(tx, e1y, -(ty * e1x));
+  const Float2 vN = fma2(r.dz, qz, fma2(r.dy, qy, r.dx * qx));
+  const Float2 wN = det - uN - vN;
+  const Float2 E = fma2(r.oInf, eb, ea);
+  const Float2 mn = (Float2){__builtin_fminf(__builtin_fminf(uN.x, vN.x), wN.x), __builtin_fminf(__builtin_fminf(uN.y, vN.y), wN.y)};
+  const Float2 mx = (Float2){__builtin_fmaxf(__builtin_fmaxf(uN.x, vN.x), wN.x), __builtin_fmaxf(__builtin_fmaxf(uN.y, vN.y), wN.y)};
+  const Float2 lo = mn + E, hi = E - mx;
+  return (Float2){__builtin_fmaxf(lo.x, hi.x), __builtin_fmaxf(lo.y, hi.y)};
+}
+
 // One sphere test, Scene.cpp:17-35.
 __device__ __forceinline__ void testSphere(d3 o, d3 d, d3 centre, double radiusSquared,
                                            uint32_t idx, double &bestT, uint32_t &bestIdx) {

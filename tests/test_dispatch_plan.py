@@ -77,6 +77,12 @@ def test_perpixel_table(pkg):
         assert plan(n, rng_policy=1, accel=2, pix_kernel=1) == "tracePerPixelPrefilter"
     with pytest.raises(pkg.PtwError):
         plan(100, rng_policy=0, accel=2)
+    with pytest.raises(pkg.PtwError):
+        plan(1000, rng_policy=0, accel=1)
+    # the prefilter form of the worker-wave kernels (SEQUENTIAL, beyond 128 triangles)
+    assert plan(970, samples_per_pixel=512, accel=2) == "traceSequential<3,6,lds,stack,2 masters,prefilter>"
+    assert plan(3442, samples_per_pixel=1024, accel=2) == "traceSequential<10,6,global,stack,2 masters,prefilter>"
+    assert plan(3442, samples_per_pixel=256, accel=2) == "traceSequential<8,7,global,stack,prefilter>"
 
 
 def test_every_planned_kernel_is_tested_on_the_gpu(pkg):
@@ -88,6 +94,8 @@ def test_every_planned_kernel_is_tested_on_the_gpu(pkg):
         for n in SIZES:
             for extra in ({}, {"seq_lds_tables": 0}, {"seq_two_masters": 1}, {"seq_two_masters": 0}):
                 produced.add(pkg.dispatch_plan(n, samples_per_pixel=passes, **extra))
+                if n > 128:
+                    produced.add(pkg.dispatch_plan(n, samples_per_pixel=passes, accel=2, **extra))
     text = "".join(p.read_text() for p in (ROOT / "tests").glob("test_gpu_*.py"))
     missing = [k for k in sorted(produced) if k.rstrip(">") not in text and k not in text]
     assert not missing, missing

@@ -5,7 +5,7 @@ import re
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", "profiles/README.md", "scripts/README.md", "profiles/bench_notes.json"]
+DOCS = ["DESIGN.md", "LAB.md", "README.md", "INTEGRATION.md", "profiles/README.md", "scripts/README.md", "profiles/bench_notes.json"]
 
 
 def _text(name):
@@ -49,6 +49,17 @@ def test_cited_tests_exist():
     assert not missing, missing
 
 
+def test_design_describes_what_ships_and_stays_short():
+    """DESIGN.md is the design that ships, at most 30 KB; the rejected designs live in LAB.md,
+    which DESIGN.md points at."""
+    design = _text("DESIGN.md")
+    assert len(design.encode()) <= 30 * 1024, len(design.encode())
+    assert "LAB.md" in design and (ROOT / "LAB.md").exists()
+    for kernel_file in ("seq_spec.hip", "seq_single.hip", "seq_worker.hip", "seq_worker2.hip", "perpixel.hip", "accel.hip",
+                        "resolve_kat.hip", "dispatch.hip"):
+        assert kernel_file in design and (ROOT / "pt-three-ways_amd" / "csrc" / kernel_file).exists(), kernel_file
+
+
 def test_reference_citations_point_at_real_lines():
     """`src/dod/Scene.cpp:124-179` and the like - in the documents, the header, the oracle, the kernels' and the
     host's comments - name a file of the reference and lines it has.  Runs where the reference is (this
@@ -57,7 +68,7 @@ def test_reference_citations_point_at_real_lines():
     ref = Path("/root/reference")
     if not (ref / "src").is_dir():
         pytest.skip("no /root/reference here")
-    files = [ROOT / d for d in ("DESIGN.md", "INTEGRATION.md", "include/ptw.h", "bench.py")]
+    files = [ROOT / d for d in ("DESIGN.md", "LAB.md", "INTEGRATION.md", "include/ptw.h", "bench.py")]
     for pattern in ("oracle/*.[ch]", "pt-three-ways_amd/csrc/*.h*",
                     "pt-three-ways_amd/host/*.*", "tests/*.py", "integration/hip/*.h"):
         files += sorted(ROOT.glob(pattern))

@@ -312,3 +312,113 @@ def test_small_scene_kernels_with_more_passes_than_cus_match_oracle(pkg, ob, ntr
     assert ctx.stats(reset=True).trace_kernel.decode() == "traceSequential<1,1,lds,reg>"
     a, b = images.values()
     assert float(np.max(np.abs(a - b) / np.maximum(np.abs(a), 1.0))) < 1e-13
+
+
+# ---- PTW_ACCEL_PREFILTER under the SEQUENTIAL policy: the worker lanes look in fp32 first -------------------------
+SEQ_PREFILTER_CASES = [   # (triangles, masters, shading tables, kernel): every instantiation the dispatcher can reach
+    (200, 1, "lds", "traceSequential<1,7,lds,stack,prefilter>"),
+    (200, 1, "global", "traceSequential<1,7,global,stack,prefilter>"),
+    (200, 2, "lds", "traceSequential<1,6,lds,stack,2 masters,prefilter>"),
+    (200, 2, "global", "traceSequential<1,6,global,stack,2 masters,prefilter>"),
+    (500, 1, "lds", "traceSequential<2,7,lds,stack,prefilter>"),
+    (500, 1, "global", "traceSequential<2,7,global,stack,prefilter>"),
+    (500, 2, "lds", "traceSequential<2,6,lds,stack,2 masters,prefilter>"),
+    (500, 2, "global", "traceSequential<2,6,global,stack,2 masters,prefilter>"),
+    (1000, 1, "lds", "traceSequential<3,7,lds,stack,prefilter>"),
+    (1000, 1, "global", "traceSequential<3,7,global,stack,prefilter>"),
+    (1000, 2, "lds", "traceSequential<3,6,lds,stack,2 masters,prefilter>"),
+    (1000, 2, "global", "traceSequential<3,6,global,stack,2 masters,prefilter>"),
+    (1200, 2, "lds", "traceSequential<4,6,lds,stack,2 masters,prefilter>"),
+    (1200, 2, "global", "traceSequential<4,6,global,stack,2 masters,prefilter>"),
+    (1350, 1, "lds", "traceSequential<4,7,lds,stack,prefilter>"),
+    (1350, 1, "global", "traceSequential<4,7,global,stack,prefilter>"),
+    (1700, 2, "global", "traceSequential<6,6,global,stack,2 masters,prefilter>"),
+    (2000, 1, "global", "traceSequential<6,7,global,stack,prefilter>"),
+    (2500, 2, "global", "traceSequential<9,6,global,stack,2 masters,prefilter>"),
+    (3000, 1, "global", "traceSequential<8,7,global,stack,prefilter>"),
+    (3300, 2, "global", "traceSequential<10,6,global,stack,2 masters,prefilter>"),   # cfg4's instantiation
+    (4600, 1, "global", "traceSequential<12,7,global,stack,prefilter>"),
+    (4600, 2, "global", "traceSequential<11,6,global,stack,2 masters,prefilter>"),   # beyond the resident slots: a streamed tail
+]
+
+
+def _seq_prefilter_render(pkg, scene, cam, w, h, spp, seed, masters, **debug):
+    import test_gpu_round3 as r3
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=seed, accel=pkg.ACCEL_PREFILTER)
+    return params, r3._render_with_stats(pkg, scene, cam, params, picks=True, seq_two_masters=1 if masters == 2 else 0, **debug)
+
+
+@pytest.mark.parametrize("ntri,masters,tables,kernel", SEQ_PREFILTER_CASES)
+def test_sequential_prefilter_worker_kernels_match_oracle(pkg, ob, monkeypatch, ntri, masters, tables, kernel):
+    """Every worker-wave instantiation in its prefilter form (SeqCtx PRE: triangles resident in fp32, two slots per
+    packed instruction, the fp64 test only for the slots fp32 cannot reject, on data fetched by the lanes that need
+    it) against the oracle on triangle soups: radiance, every sample's RNG word count and pick checksum - one band
+    with an odd pass count, and parked streams under a tiny staging budget."""
+    import test_gpu_round3 as r3
+    for spp, budget_kb in ((3, None), (2, 1)):
+        monkeypatch.delenv("PTW_STAGE_BUDGET_KB", raising=False)
+        if budget_kb:
+            monkeypatch.setenv("PTW_STAGE_BUDGET_KB", str(budget_kb))
+        w, h = (12, 10) if budget_kb else (4, 3)
+        scene, cam = r3._soup(pkg, ntri, 2, seed=13 * ntri + spp, w=w, h=h)
+        debug = {"seq_lds_tables": 0} if tables == "global" and ntri < 1400 else {}
+        params, (rgb, cnt, words, variant, launches, picks) = _seq_prefilter_render(pkg, scene, cam, w, h, spp, 4, masters, **debug)
+        ref_rgb, ref_cnt, ref_words, ref_picks = ob.oracle_render_picks(scene.view(), cam, params, threads=3)
+        assert variant == kernel, variant
+        assert not budget_kb or launches > 1
+        assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words)
+        assert np.array_equal(picks, ref_picks), "a ray hit another primitive than in the oracle"
+        assert rel_err(rgb, ref_rgb) < TOL
+
+
+@pytest.mark.parametrize("name,edge,spp,masters", [("suzanne", 16, 6, 2), ("suzanne", 12, 3, 1), ("ce", 6, 5, 2), ("ce", 6, 2, 1)])
+def test_sequential_prefilter_on_the_baseline_scenes_writes_the_plain_kernels_bytes(pkg, ob, name, edge, spp, masters):
+    """cfg3's and cfg4's scenes: the prefilter form against the oracle (with picks) AND against the plain worker-wave
+    kernel's fp64 sums, byte for byte - the two differ in which tests they skip, never in a value."""
+    import test_gpu_round3 as r3
+    scene = pkg.Scene()
+    cam = scene.build_named(name, edge, edge)
+    params, (rgb, cnt, words, variant, _, picks) = _seq_prefilter_render(pkg, scene, cam, edge, edge, spp, 1, masters)
+    assert variant.endswith(",prefilter>"), variant
+    ref_rgb, ref_cnt, ref_words, ref_picks = ob.oracle_render_picks(scene.view(), cam, params, threads=6)
+    assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words) and np.array_equal(picks, ref_picks)
+    assert rel_err(rgb, ref_rgb) < TOL
+    plain = pkg.default_params(width=edge, height=edge, samples_per_pixel=spp, seed=1)
+    rgb0, cnt0, words0, variant0, _ = r3._render_with_stats(pkg, scene, cam, plain, seq_two_masters=1 if masters == 2 else 0)
+    assert not variant0.endswith(",prefilter>") and np.array_equal(rgb0, rgb) and np.array_equal(words0, words)
+
+
+def test_sequential_prefilter_resolves_exact_ties_like_the_reference(pkg, ob):
+    """Duplicated triangles (exact ties in t, in the same lane's other slot, in another lane, in another wave) with
+    OTHER materials: the first-inserted one must win under the prefilter form too - its survivors are tested lowest
+    slot first, strictly-nearer wins (src/dod/Scene.cpp:95)."""
+    rng = np.random.default_rng(11)
+    scene = pkg.Scene()
+    mats = [pkg.material("diffuse", (0.9, 0.2, 0.2)), pkg.material("light", (2.5, 2.0, 1.5)), pkg.material("diffuse", (0.2, 0.9, 0.2)),
+            pkg.material("glossy", (0.4, 0.4, 0.9), 1.3, 25.0), pkg.material("reflective", (0.8, 0.8, 0.8), 0.6, 6.0)]
+    nbase = 400
+    base = rng.uniform(-2.5, 2.5, (nbase, 3))[:, None, :] + rng.uniform(-1.0, 1.0, (nbase, 3, 3))
+    for k, t in enumerate(base):
+        scene.add_triangle(*t, mats[k % 5])
+    for shift in (1, 2, 3):                       # three more copies of every triangle: 64, 400 and 800 indices later
+        for k, t in enumerate(base):
+            scene.add_triangle(*t, mats[(k + shift) % 5])
+    scene.add_sphere((0, 0, 0), 9.0, mats[0])
+    scene.set_environment_colour((0.1, 0.2, 0.3))
+    w, h = 10, 8
+    cam = pkg.set_focus(pkg.look_at((0, 0.3, 6.5), (0, 0, 0), (0, 1, 0), w, h, 50.0), (0, 0, 0), 0.02)
+    for masters in (2, 1):
+        params, (rgb, cnt, words, variant, _, picks) = _seq_prefilter_render(pkg, scene, cam, w, h, 3, 21, masters)
+        ref_rgb, ref_cnt, ref_words, ref_picks = ob.oracle_render_picks(scene.view(), cam, params, threads=3)
+        assert variant.endswith(",prefilter>"), variant
+        assert np.array_equal(words, ref_words), "a tie was resolved differently from the reference"
+        assert np.array_equal(picks, ref_picks), "a tie went to another primitive than in the reference"
+        assert rel_err(rgb, ref_rgb) < TOL
+
+
+def test_sequential_prefilter_is_refused_for_small_scenes(pkg):
+    scene = pkg.Scene()
+    cam = scene.build_named("cornell", 8, 8)
+    with pytest.raises(pkg.PtwError) as e:
+        pkg.render(scene, cam, pkg.default_params(width=8, height=8, samples_per_pixel=1, seed=1, accel=pkg.ACCEL_PREFILTER))
+    assert e.value.status == 8 and "128" in str(e.value)

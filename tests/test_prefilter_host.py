@@ -11,7 +11,7 @@ either side of them, from near and far, on triangles from 1e-6 to 1e4 in size, s
 import numpy as np
 import pytest
 
-EPS = 1e-7   # Epsilon, src/math/Epsilon.h (kEpsilon)
+EPS = 1e-9   # Epsilon, src/math/Epsilon.h:3 (kEpsilon)
 f32 = np.float32
 
 
