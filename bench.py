@@ -365,7 +365,7 @@ def cpu_leg(pkg, ob, scene_name, threads, passes, frame):
 
 
 def parity_vs_reference(pkg, ob, ctx, cam, view, scene_name, w, h, total_spp, seed, passes, rows_end, threads,
-                        want_picks=False):
+                        want_picks=False, accel=0):
     """The metric's second half: renders rows [0, rows_end) of the w x h frame once more on the GPU
     with per-sample RNG word counts (rows_end == h: the whole frame), runs the reference's own code
     for the same passes on the host cores, and compares every pixel and every sample's word count.
@@ -378,7 +378,7 @@ def parity_vs_reference(pkg, ob, ctx, cam, view, scene_name, w, h, total_spp, se
     rows_end = min(rows_end, h)
     window = dict(row_begin=0, row_end=rows_end) if rows_end < h else {}
     params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=seed,
-                                rng_policy=pkg.RNG_SEQUENTIAL, **window)
+                                rng_policy=pkg.RNG_SEQUENTIAL, accel=accel, **window)   # (accel: `--accel prefilter` lines)
     rgb = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
     cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
     words = torch.zeros((spp, h, w), dtype=torch.int32, device="cuda")
@@ -889,7 +889,8 @@ def main():
             passes = 12 if passes is None else passes
             parity, all_cores_leg = parity_vs_reference(pkg, ob, ctx, cam, view, args.scene, w, h, spp, args.seed,
                                                         passes, rows_end, usable_cpus(),
-                                                        want_picks=args.config in SIDE_PARITY)
+                                                        want_picks=args.config in SIDE_PARITY,
+                                                        accel=pkg.ACCEL_PREFILTER if args.accel == "prefilter" else 0)
             result.update(parity)
             legs.append(all_cores_leg)
         if not args.no_cpu_baseline:
