@@ -532,8 +532,7 @@ def side_config(pkg, ob, name, device, threads, want_parity, want_cpu=False, cpu
         st2 = ctx.stats(reset=True)
         ctx.enable_stats(False)
         out["prefilter_mode"] = {"value": w * rows * spp / dt2 / 1e6, "kernel": st2.trace_kernel.decode(),
-                                 "same_bytes": bool(torch.equal(rgb, rgb2) and torch.equal(cnt, cnt2)),
-                                 "note": "separate mode: fp32 look before the fp64 test, same image"}
+                                 "same_bytes": bool(torch.equal(rgb, rgb2) and torch.equal(cnt, cnt2))}
         del rgb2, cnt2
     if want_parity:
         par, leg = parity_vs_reference(pkg, ob, ctx, cam, view, cfg["scene"], w, h, spp, 1,
@@ -555,7 +554,7 @@ def accel_leg(pkg, device):
     """The SEPARATE accelerated modes of SURVEY 8 f4 (PERPIXEL policy; never the headline): the brute-force
     kernel, the conservative fp32 prefilter (every triangle still looked at) and the BVH on the
     two large scenes, one timed render each, and whether the three images are the same BYTES."""
-    out = {"note": "separate modes, perpixel policy, never the headline; Msamples/s"}
+    out = {}   # (what the fields mean: profiles/bench_notes.json, `accel_modes`)
     for name, edge, spp in (("suzanne", 1024, 16), ("ce", 512, 16)):
         scene = pkg.Scene()
         cam = scene.build_named(name, edge, edge)

@@ -249,7 +249,8 @@ typedef struct ptw_debug_options {
                                    plain single-wave kernel (LDS tables, LDS stack), 1 the register
                                    variant, 2 the speculative four-wave kernel whatever the pass count,
                                    3 that kernel in its round-5 form (no camera ray of the next pixel
-                                   traced ahead in a pixel's last round) - the A/B switch of round 6     */
+                                   traced ahead in a pixel's last round) - the A/B switch of round 6 -,
+                                   4 its two-wave form (frontier + one candidate, two workgroups per CU) */
   int32_t seq_units[3];         /* worker-wave kernels: resident units of 64 triangles of an older /
                                    younger / master-side worker wave; {0, 0, 0} = the library's split */
   int32_t pix_samples_per_lane; /* lock-step PERPIXEL kernel's grid-stride depth; 0 = default (8)     */
@@ -335,7 +336,7 @@ int ptw_context_render(ptw_context *ctx, const ptw_camera *camera,
  * 16 M samples or more.  Under PTW_RNG_SEQUENTIAL / the accelerated mode: PTW_PIX_KERNEL_AUTO, no
  * trial. */
 /* (Round 6: under PTW_RNG_SEQUENTIAL the same call times the two small-scene kernels - one wave per pass
- * against four speculating waves - when the scene has at most 64 triangles and the launch between one and six
+ * against four speculating waves against two - when the scene has at most 64 triangles and the launch between one and six
  * passes per compute unit, where which one wins depends on the scene; the context remembers the winner for this
  * scene, camera, frame shape and pass count, *kernel_out is PTW_PIX_KERNEL_AUTO.  A no-op for every other launch.) */
 int ptw_context_calibrate(ptw_context *ctx, const ptw_camera *camera,

@@ -303,34 +303,40 @@ int calibrateSeqSmall(ptw_context &ctx, const TraceParams &t, const TraceBuffers
   if (tt.pixCount < 16) return 0; // (too small a frame to tell, or to matter)
   TraceBuffers bb = b;
   bb.rays = nullptr, bb.words = nullptr, bb.picks = nullptr;
-  hipEvent_t ev[3];
+  // the three candidates (ptw_debug_options.seq_small_kernel's values): one wave per pass, four speculating waves (a
+  // CU per pass, in turns), two speculating waves (two workgroups per CU)
+  constexpr int kKinds = 3;
+  const int kind[kKinds] = {1, 2, 4};
+  hipEvent_t ev[kKinds + 1];
   for (auto &e : ev) check(hipEventCreate(&e), "hipEventCreate");
-  float ms[2] = {0, 0};
+  float ms[kKinds] = {0, 0, 0};
   try {
     for (int warm = 1; warm >= 0; --warm) { // first pass: code objects loaded, tiny; second: timed
       TraceParams run = tt;
       if (warm) run.pixCount = 4;
       check(hipEventRecord(ev[0], stream), "hipEventRecord");
-      hints.seqSmallKernel = 1;
-      check(launchTraceSequential(run, bb, hints, stream), "trial launch");
-      check(hipEventRecord(ev[1], stream), "hipEventRecord");
-      hints.seqSmallKernel = 2;
-      check(launchTraceSequential(run, bb, hints, stream), "trial launch");
-      check(hipEventRecord(ev[2], stream), "hipEventRecord");
+      for (int k = 0; k < kKinds; ++k) {
+        hints.seqSmallKernel = kind[k];
+        check(launchTraceSequential(run, bb, hints, stream), "trial launch");
+        check(hipEventRecord(ev[k + 1], stream), "hipEventRecord");
+      }
     }
-    check(hipEventSynchronize(ev[2]), "hipEventSynchronize");
-    check(hipEventElapsedTime(&ms[0], ev[0], ev[1]), "hipEventElapsedTime");
-    check(hipEventElapsedTime(&ms[1], ev[1], ev[2]), "hipEventElapsedTime");
+    check(hipEventSynchronize(ev[kKinds]), "hipEventSynchronize");
+    for (int k = 0; k < kKinds; ++k) check(hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]), "hipEventElapsedTime");
   } catch (...) {
     for (auto &e : ev) (void)hipEventDestroy(e);
     throw;
   }
   for (auto &e : ev) (void)hipEventDestroy(e);
+  int best = 0;
+  for (int k = 1; k < kKinds; ++k)
+    if (ms[k] < ms[best]) best = k;
   ctx.seqSmallChoiceKey = seqSmallChoiceKeyOf(ctx, t);
-  ctx.seqSmallChoice = ms[0] <= ms[1] ? 1 : 2;
+  ctx.seqSmallChoice = kind[best];
   if (ctx.debug.trace)
     std::fprintf(stderr, "ptw: SEQUENTIAL small-scene trial (%u pixels x %u passes): one wave per pass %.3f ms, four speculating "
-                         "waves %.3f ms -> %s\n", tt.pixCount, tt.npass, ms[0], ms[1], ctx.seqSmallChoice == 1 ? "one wave" : "speculative");
+                         "waves %.3f ms, two speculating waves %.3f ms -> seq_small_kernel %d\n", tt.pixCount, tt.npass, ms[0], ms[1],
+                 ms[2], ctx.seqSmallChoice);
   return ctx.seqSmallChoice;
 }
 
@@ -1043,6 +1049,11 @@ void renderMulti(const ptw_scene_view &scene, const ptw_camera &camera,
             check(hipMemsetAsync(sh.rgb.ptr, 0, npix * 3 * sizeof(double), sh.stream), "memset");
             check(hipMemsetAsync(sh.counts.ptr, 0, npix * sizeof(uint32_t), sh.stream), "memset");
           }
+          // (SEQUENTIAL, a small scene, this shard's pass count between one and six per CU - cfg5's per-GPU share:
+          // every shard times the small-scene kernels on its own device; same bytes whichever wins)
+          if (wantsSeqCalibration(sh.params))
+            if (int rc = ptw_context_calibrate(sh.ctx.get(), &camera, &sh.params, sh.stream, nullptr); rc != PTW_OK)
+              throw DeviceError(rc, ptw_last_error());
           enqueueRender(*sh.ctx, camera, sh.params, sh.rgb.ptr, sh.counts.ptr, nullptr, sh.stream,
                         g == 0 && opt.progress ? 20 : 0,
                         [&](const TraceParams &, uint64_t done, uint64_t totalSamples) {

@@ -70,7 +70,7 @@ hipError_t dispatchSequential(const TraceParams &p, const TraceBuffers &b, const
     // kernel spends a whole CU on a pass.  That pays while there are at most as many passes as CUs;
     // with more, one wave per pass on every SIMD is the better use of the chip.
     const int cus = cusFor(hints);
-    const bool forced = hints.seqSmallKernel == 2 || hints.seqSmallKernel == 3; // whatever the pass count
+    const bool forced = hints.seqSmallKernel >= 2 && hints.seqSmallKernel <= 4; // whatever the pass count
     if (reg && hints.seqSmallKernel != 1 && b.specState && (forced || p.npass <= static_cast<uint32_t>(cus)))
       return launchSeqSpec(p, b, hints, stream);
     return launchSeqSingle(p, b, hints, stream, 1, reg);

@@ -50,7 +50,7 @@ struct alignas(16) PrimRec {
 static_assert(sizeof(PrimRec) == 64, "PrimRec layout");
 constexpr size_t kSpecPrimBytes = 2 * kSpecWaves * sizeof(PrimRec);
 
-__host__ __device__ inline size_t specLdsBytes(uint32_t ntri, uint32_t nmat, uint32_t nsph) {
+__host__ __device__ inline size_t specLdsBytes(uint32_t ntri, uint32_t nmat, uint32_t nsph, bool wholeCu = true) {
   size_t n = 2 * kRingStride;                          // the ring
   n += kMtWords * sizeof(uint32_t);                    // raw generator state
   n += 2 * kSpecWaves * sizeof(SpecResult);            // results, double-buffered
@@ -59,19 +59,27 @@ __host__ __device__ inline size_t specLdsBytes(uint32_t ntri, uint32_t nmat, uin
   n += static_cast<size_t>(nsph) * sizeof(SphereRec);
   n += static_cast<size_t>(ntri) * kTriCompactDoubles * sizeof(double);
   n += static_cast<size_t>(nmat) * kMatDoubles * sizeof(double);
-  // more than half of a CU's 160 KB: one workgroup per CU, so its four waves get a SIMD each
-  const size_t floor = 84 * 1024;
+  // more than half of a CU's 160 KB: one workgroup per CU, so its four waves get a SIMD each.  (Not for the
+  // two-wave form: two of its workgroups - three waves each - share a CU, which is what fills the SIMDs when there
+  // are two passes per CU.)
+  const size_t floor = wholeCu ? 84 * 1024 : 0;
   return n < floor ? floor : n;
 }
 
-template <bool PICKS, bool CROSS>
-__global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
+// NW: tracing waves per pass.  4: the form described above (a CU per pass).  2 (round 6; more passes than CUs): the
+// frontier plus ONE candidate - sub-sample j+1 assuming m1 - and two workgroups per CU: with between one and two
+// passes per CU it fills the SIMDs that one wave per pass leaves empty (1.5 commits per round instead of 2.04; the
+// LDS areas keep their four-wave layout, slots 2 and 3 are never written and never read).
+template <bool PICKS, bool CROSS, int NW = kSpecWaves>
+__global__ __launch_bounds__(64 * (NW + 1)) void traceSequentialSpec(
     const TraceParams p, const double *__restrict__ triGeom, const SphereRec *__restrict__ spheres,
     const double *__restrict__ triCompact, const double *__restrict__ matTable,
     uint32_t *__restrict__ mtState, double *__restrict__ specState, double *__restrict__ stage,
     uint32_t *__restrict__ words, unsigned long long *__restrict__ rayCounters, uint32_t *__restrict__ picks) {
   extern __shared__ __attribute__((aligned(64))) unsigned char ldsRaw[];
-  constexpr int kBlock = 64 * (kSpecWaves + 1);
+  static_assert(NW == 2 || NW == kSpecWaves, "two or four tracing waves");
+  constexpr int kBlock = 64 * (NW + 1);
+  constexpr int has23 = NW > 2 ? -1 : 0; // (all-ones / zero mask: waves 2 and 3 exist)
   char *ring = reinterpret_cast<char *>(ldsRaw);
   uint32_t *mt = reinterpret_cast<uint32_t *>(ldsRaw + 2 * kRingStride);
   SpecResult *results = reinterpret_cast<SpecResult *>(mt + kMtWords);
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
     ctx.tab.tri = lt;
     ctx.tab.mat = lm;
   }
-  const bool isGenerator = wave == kSpecWaves; // the fifth wave only produces the stream
+  const bool isGenerator = wave == NW; // the last wave only produces the stream
   if (!isGenerator) ctx.loadPrimitives();
 
   // ---- the stream: resume (or start) this pass's generator ring ----
@@ -410,10 +418,10 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
           const int d1 = m1, d2 = oneMode ? 3 * m1 : m2, d3v = 2 * m1;
           const int w2Second = oneMode ? 0 : -1; // wave 2 ran sub-sample j+1 (else j+3)
           const int ok1 = lt(j + 1, nSub) & eq(d1, c0);
-          const int ok2a = lt(j + 1, nSub) & ~ok1 & w2Second & eq(d2, c0);
+          const int ok2a = has23 & lt(j + 1, nSub) & ~ok1 & w2Second & eq(d2, c0);
           const int cur1 = c0 + (c1 & ok1) + (c2 & ok2a);
           const int two = ok1 | ok2a;
-          const int ok3 = two & lt(j + 2, nSub) & eq(d3v, cur1);
+          const int ok3 = has23 & two & lt(j + 2, nSub) & eq(d3v, cur1);
           const int cur2 = cur1 + (c3 & ok3);
           const int ok2b = ok3 & lt(j + 3, nSub) & ~w2Second & eq(d2, cur2);
           const int cur = cur2 + (c2 & ok2b);
@@ -476,8 +484,8 @@ __global__ __launch_bounds__(64 * (kSpecWaves + 1)) void traceSequentialSpec(
           auto eq = [](int a, int b) { return ((a ^ b) - 1) >> 31; }; // a, b >= 0: -1 if equal
           const int ioff2 = lastOne ? 3 : 1;
           const int p1 = eq(lastJ + 1, nSub) & eq(lastD1, lastCur);
-          const int p2 = eq(lastJ + ioff2, nSub) & eq(lastD2, lastCur);
-          const int p3 = eq(lastJ + 2, nSub) & eq(lastD3, lastCur);
+          const int p2 = has23 & eq(lastJ + ioff2, nSub) & eq(lastD2, lastCur);
+          const int p3 = has23 & eq(lastJ + 2, nSub) & eq(lastD3, lastCur);
           primWave = p1 ? 1 : (p2 ? 2 : (p3 ? 3 : 0));
         }
       }
@@ -534,20 +542,22 @@ bool specApplies(const TraceParams &p) {
 }
 
 hipError_t launchSeqSpec(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream) {
-  // (LaunchHints::seqSmallKernel == 3: round 5's form, without the next pixel's primary ray traced ahead)
-  const bool ahead = hints.seqSmallKernel != 3;
-  setVariant(ahead ? "traceSequentialSpec" : "traceSequentialSpec<no cross-pixel candidate>");
+  // (LaunchHints::seqSmallKernel == 3: round 5's form, without the next pixel's primary ray traced ahead; 4: the
+  // two-wave form, two workgroups per CU)
+  const bool ahead = hints.seqSmallKernel != 3, two = hints.seqSmallKernel == 4;
+  setVariant(two ? "traceSequentialSpec<2 waves>" : ahead ? "traceSequentialSpec" : "traceSequentialSpec<no cross-pixel candidate>");
   if (hints.dryRun) return hipSuccess;
-  const size_t lds = specLdsBytes(p.ntri, p.nmat, p.nsph);
-  auto kernel = b.picks ? (ahead ? traceSequentialSpec<true, true> : traceSequentialSpec<true, false>)
-                        : (ahead ? traceSequentialSpec<false, true> : traceSequentialSpec<false, false>);
+  const size_t lds = specLdsBytes(p.ntri, p.nmat, p.nsph, !two);
+  auto kernel = two ? (b.picks ? traceSequentialSpec<true, true, 2> : traceSequentialSpec<false, true, 2>)
+                    : b.picks ? (ahead ? traceSequentialSpec<true, true> : traceSequentialSpec<true, false>)
+                              : (ahead ? traceSequentialSpec<false, true> : traceSequentialSpec<false, false>);
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds));
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kernel, dim3(p.npass), dim3(64 * (kSpecWaves + 1)), lds, stream, p,
+  hipLaunchKernelGGL(kernel, dim3(p.npass), dim3(64 * ((two ? 2 : kSpecWaves) + 1)), lds, stream, p,
                      b.triGeom, b.spheres, b.triCompact, b.matTable, b.mtState, b.specState, b.stage,
                      b.words, b.rays, b.picks);
   return hipGetLastError();

@@ -64,6 +64,7 @@ def test_thresholds(pkg):
     assert plan(970, samples_per_pixel=512, seq_two_masters=0) == "traceSequential<3,7,lds,stack>"
     assert plan(40, samples_per_pixel=1024, seq_small_kernel=2) == "traceSequentialSpec"
     assert plan(40, seq_small_kernel=3) == "traceSequentialSpec<no cross-pixel candidate>"
+    assert plan(40, samples_per_pixel=512, seq_small_kernel=4) == "traceSequentialSpec<2 waves>"
     assert plan(200, samples_per_pixel=512, seq_lds_tables=0) == "traceSequential<1,6,global,stack,2 masters>"
 
 

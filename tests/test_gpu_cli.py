@@ -75,6 +75,9 @@ def test_sequential_kernel_variants_write_identical_bytes(pkg, tmp_path, scene, 
                 # round 5's form of the speculative kernel: without the next pixel's camera ray traced ahead
                 "spec_no_cross": ({}, {"seq_small_kernel": 3}),
                 "spec_no_cross_bands": ({"PTW_STAGE_BUDGET_KB": "12"}, {"seq_small_kernel": 3}),
+                # the two-wave form (frontier + one candidate, two workgroups per CU: more passes than CUs)
+                "spec_two_waves": ({}, {"seq_small_kernel": 4}),
+                "spec_two_waves_bands": ({"PTW_STAGE_BUDGET_KB": "12"}, {"seq_small_kernel": 4}),
                 }
     blobs = {}
     for name, (env, debug) in variants.items():

@@ -550,6 +550,7 @@ SMALL_SCENE_CASES = [
 
 @pytest.mark.parametrize("kernel,debug", [("traceSequentialSpec", {}),
                                           ("traceSequentialSpec<no cross-pixel candidate>", dict(seq_small_kernel=3)),
+                                          ("traceSequentialSpec<2 waves>", dict(seq_small_kernel=4)),
                                           ("traceSequential<1,1,lds,reg>", dict(seq_small_kernel=1)),
                                           ("traceSequential<1,1,lds,stack>", dict(seq_small_kernel=0))])
 def test_small_scene_kernels_match_oracle(pkg, ob, monkeypatch, kernel, debug):

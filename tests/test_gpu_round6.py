@@ -282,7 +282,8 @@ def test_small_scene_kernels_with_more_passes_than_cus_match_oracle(pkg, ob, ntr
     params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=1)
     ref_rgb, ref_cnt, ref_words, ref_picks = ob.oracle_render_picks(scene.view(), cam, params, threads=8)
     images = {}
-    for name, debug in (("traceSequentialSpec", dict(seq_small_kernel=2)), ("traceSequential<1,1,lds,reg>", dict(seq_small_kernel=1))):
+    for name, debug in (("traceSequentialSpec", dict(seq_small_kernel=2)), ("traceSequential<1,1,lds,reg>", dict(seq_small_kernel=1)),
+                        ("traceSequentialSpec<2 waves>", dict(seq_small_kernel=4))):
         rgb, cnt, words, variant, _, picks = r3._render_with_stats(pkg, scene, cam, params, picks=True, **debug)
         assert variant == name, variant
         assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words) and np.array_equal(picks, ref_picks), name
@@ -291,7 +292,7 @@ def test_small_scene_kernels_with_more_passes_than_cus_match_oracle(pkg, ob, ntr
     # the dispatcher on its own: the static rule says one wave per pass ...
     rgb, cnt, words, variant, _ = r3._render_with_stats(pkg, scene, cam, params)
     assert variant == "traceSequential<1,1,lds,reg>", variant
-    # ... and after the timed trial the kernel that measured faster - on a closed scene the speculative one
+    # ... and after the timed trial the kernel that measured fastest - on a closed scene a speculative one
     ctx = pkg.Context(0)
     ctx.set_scene(scene)
     ctx.enable_stats(True)
@@ -303,15 +304,16 @@ def test_small_scene_kernels_with_more_passes_than_cus_match_oracle(pkg, ob, ntr
     ctx.render(cam, params, rgb_t.data_ptr(), cnt_t.data_ptr(), words_t.data_ptr(), st)
     torch.cuda.synchronize()
     chosen = ctx.stats(reset=True).trace_kernel.decode()
-    assert chosen == "traceSequentialSpec", chosen
+    assert chosen in ("traceSequentialSpec", "traceSequentialSpec<2 waves>"), chosen
     assert np.array_equal(words_t.cpu().numpy().astype(np.uint32), ref_words) and rel_err(rgb_t.cpu().numpy(), ref_rgb) < TOL
     # another pass count: the measurement does not carry over
     p2 = pkg.default_params(width=w, height=h, samples_per_pixel=spp + 1, seed=1)
     ctx.render(cam, p2, rgb_t.data_ptr(), cnt_t.data_ptr(), 0, st)
     torch.cuda.synchronize()
     assert ctx.stats(reset=True).trace_kernel.decode() == "traceSequential<1,1,lds,reg>"
-    a, b = images.values()
-    assert float(np.max(np.abs(a - b) / np.maximum(np.abs(a), 1.0))) < 1e-13
+    a, b, c = images.values()
+    for other in (b, c):
+        assert float(np.max(np.abs(a - other) / np.maximum(np.abs(a), 1.0))) < 1e-13
 
 
 # ---- PTW_ACCEL_PREFILTER under the SEQUENTIAL policy: the worker lanes look in fp32 first -------------------------
