@@ -32,8 +32,7 @@ namespace {
 // the slot that just became free.
 // -----------------------------------------------------------------------------------------
 constexpr int kSpecWaves = 4;
-
-struct alignas(16) SpecResult { // one per wave and round parity, in LDS
+struct alignas(16) SpecResult { // one per wave and result set, in LDS
   double L[3]; // radiance of the sub-path below the first-bounce surface
   int meta;    // canonical doubles consumed | lobe at the first-bounce surface << 8 | rays << 16
   int pad;
@@ -50,11 +49,53 @@ struct alignas(16) PrimRec {
 static_assert(sizeof(PrimRec) == 64, "PrimRec layout");
 constexpr size_t kSpecPrimBytes = 2 * kSpecWaves * sizeof(PrimRec);
 
-__host__ __device__ inline size_t specLdsBytes(uint32_t ntri, uint32_t nmat, uint32_t nsph, bool wholeCu = true) {
+// The GENERATOR wave - idle except once per 312 draws - adds the committed radiance in sub-sample order and stores the
+// sample: with every barrier the tracing waves tell it which of the PREVIOUS round's results were committed, and it
+// folds them while the next round is being traced (three result sets in turn: a set is read one round late).  That
+// takes the fold (two LDS round trips and fifteen vector instructions per committed sub-sample) off the tracing waves'
+// path between two rounds: +2.8 % on Cornell together with the one-note histogram below (LAB.md, round 6).
+// What the generator needs to know about a pixel whose fan-out it sums: the first-bounce surface's
+// emission and diffuse colour, the pixel's index in the band, the pick checksum's term of the primary ray.
+// Three records in turn for the pixels that have a fan-out: a pixel's record is read one barrier after its first
+// round's, and a pixel can be over in one round - the record written two such pixels later must be another one.
+struct alignas(16) PixFin {
+  double e[3], dif[3];
+  uint32_t pixel, pick0;
+  uint32_t pad[2];
+};
+static_assert(sizeof(PixFin) == 64, "PixFin layout");
+constexpr int kSpecResultSets = 3; // result sets (the generator reads a round's set one barrier later)
+// The word the tracing waves hand the generator with every barrier: bits 0-1 the stream command (kGen*), and -
+// bit 2: bits 3-12 describe a committed round; bits 3-6: ok1, ok2a, ok3, ok2b (wave 0's result always
+// counts); bits 7-8: the round's result set; bit 9: first round of its pixel (take PixFin[bits 10-11]); bit 12: last.
+constexpr uint32_t kFinValid = 4, kFinOk1 = 8, kFinOk2a = 16, kFinOk3 = 32, kFinOk2b = 64, kFinSetShift = 7,
+                   kFinFirst = 512, kFinRecShift = 10, kFinLast = 4096;
+constexpr int kSpecPixFins = 3;
+
+// FAN (round 6, the four-wave form): the first-bounce scatter of a sub-sample - stratify, one sincos, two square roots
+// - depends on the draws at its stream position and on its stratum only, like the deeper levels' local directions
+// (SeqShared::hemi).  For fan-outs of at most 4 x 4 strata the generator side computes, per position q of a block and
+// stratum k of each axis, (cos, sin)(2 pi u_k(canon[q])) and (sqrt v_k, sqrt(1 - v_k))(canon[q + 1]) with the very
+// functions hemisphereSample() calls - 16 doubles per position, 39 KB per block - so that a tracing wave's task starts
+// with two 16-byte LDS reads and two multiplications where it evaluated ~110 vector instructions.  FOUR generator
+// waves, one per SIMD, build a quarter each in the issue slots their tracing wave leaves empty, one barrier after the
+// block's draws exist; a counter per slot says when a generation is complete, and a task whose table is not (or whose
+// position is the block's last: its v needs the next block) evaluates the scatter itself as before - same values.
+constexpr int kFanStrata = 4;
+constexpr int kFanEntryDoubles = 4 * kFanStrata;
+constexpr size_t kFanSlotBytes = static_cast<size_t>(kMtDoubles) * kFanEntryDoubles * sizeof(double);
+constexpr int kSpecGens = 4; // generator waves of the FAN form
+#ifndef PTW_SPEC_FAN
+#define PTW_SPEC_FAN 1
+#endif
+constexpr size_t kSpecLdsLimit = PTW_SPEC_FAN ? 160 * 1024 : 0; // a gfx950 workgroup's LDS (0: A/B build without the tables)
+
+__host__ __device__ inline size_t specLdsBytes(uint32_t ntri, uint32_t nmat, uint32_t nsph, bool wholeCu = true, bool fan = false) {
   size_t n = 2 * kRingStride;                          // the ring
   n += kMtWords * sizeof(uint32_t);                    // raw generator state
-  n += 2 * kSpecWaves * sizeof(SpecResult);            // results, double-buffered
+  n += kSpecResultSets * kSpecWaves * sizeof(SpecResult); // results: three sets in turn
   n += 64 + kSeqCamBytes + kSpecPrimBytes;             // generator commands, the camera, the primary-ray records
+  n += kSpecPixFins * sizeof(PixFin);
   n = (n + 63) & ~static_cast<size_t>(63);
   n += static_cast<size_t>(nsph) * sizeof(SphereRec);
   n += static_cast<size_t>(ntri) * kTriCompactDoubles * sizeof(double);
@@ -62,6 +103,7 @@ __host__ __device__ inline size_t specLdsBytes(uint32_t ntri, uint32_t nmat, uin
   // more than half of a CU's 160 KB: one workgroup per CU, so its four waves get a SIMD each.  (Not for the
   // two-wave form: two of its workgroups - three waves each - share a CU, which is what fills the SIMDs when there
   // are two passes per CU.)
+  if (fan) n = ((n + 127) & ~static_cast<size_t>(127)) + 2 * kFanSlotBytes;
   const size_t floor = wholeCu ? 84 * 1024 : 0;
   return n < floor ? floor : n;
 }
@@ -70,30 +112,34 @@ __host__ __device__ inline size_t specLdsBytes(uint32_t ntri, uint32_t nmat, uin
 // frontier plus ONE candidate - sub-sample j+1 assuming m1 - and two workgroups per CU: with between one and two
 // passes per CU it fills the SIMDs that one wave per pass leaves empty (1.5 commits per round instead of 2.04; the
 // LDS areas keep their four-wave layout, slots 2 and 3 are never written and never read).
-template <bool PICKS, bool CROSS, int NW = kSpecWaves>
-__global__ __launch_bounds__(64 * (NW + 1)) void traceSequentialSpec(
+template <bool PICKS, bool CROSS, int NW = kSpecWaves, bool FAN = false>
+__global__ __launch_bounds__(64 * (NW + (FAN ? kSpecGens : 1))) void traceSequentialSpec(
     const TraceParams p, const double *__restrict__ triGeom, const SphereRec *__restrict__ spheres,
     const double *__restrict__ triCompact, const double *__restrict__ matTable,
     uint32_t *__restrict__ mtState, double *__restrict__ specState, double *__restrict__ stage,
     uint32_t *__restrict__ words, unsigned long long *__restrict__ rayCounters, uint32_t *__restrict__ picks) {
   extern __shared__ __attribute__((aligned(64))) unsigned char ldsRaw[];
   static_assert(NW == 2 || NW == kSpecWaves, "two or four tracing waves");
-  constexpr int kBlock = 64 * (NW + 1);
+  static_assert(!FAN || NW == kSpecWaves, "the first-bounce tables exist for the four-wave form");
+  constexpr int kGens = FAN ? kSpecGens : 1;
+  constexpr int kBlock = 64 * (NW + kGens);
   constexpr int has23 = NW > 2 ? -1 : 0; // (all-ones / zero mask: waves 2 and 3 exist)
   char *ring = reinterpret_cast<char *>(ldsRaw);
   uint32_t *mt = reinterpret_cast<uint32_t *>(ldsRaw + 2 * kRingStride);
   SpecResult *results = reinterpret_cast<SpecResult *>(mt + kMtWords);
   // (taken from ldsRaw inside the lambdas too: a captured pointer loses its LDS address space and
   // the stores turn into flat instructions with a vmcnt wait)
-  constexpr size_t kGenCmdOffset = 2 * kRingStride + kMtWords * sizeof(uint32_t) + 2 * kSpecWaves * sizeof(SpecResult);
+  constexpr size_t kGenCmdOffset = 2 * kRingStride + kMtWords * sizeof(uint32_t) + kSpecResultSets * kSpecWaves * sizeof(SpecResult);
   uint32_t *genCmd = reinterpret_cast<uint32_t *>(ldsRaw + kGenCmdOffset);
-  size_t off = 2 * kRingStride + kMtWords * sizeof(uint32_t) + 2 * kSpecWaves * sizeof(SpecResult) + 64;
+  size_t off = kGenCmdOffset + 64;
   // (the camera in LDS: as part of the kernel argument its 36 dwords were spilled to vector-register lanes
   // and read back for every pixel - see kSeqCamBytes)
   ptw_camera *camLds = reinterpret_cast<ptw_camera *>(ldsRaw + off);
   off += kSeqCamBytes;
   PrimRec *primRecs = reinterpret_cast<PrimRec *>(ldsRaw + off); // [pixel parity][wave]
   off += kSpecPrimBytes;
+  PixFin *pixFin = reinterpret_cast<PixFin *>(ldsRaw + off);
+  off += kSpecPixFins * sizeof(PixFin);
   off = (off + 63) & ~static_cast<size_t>(63);
   if (threadIdx.x < sizeof(ptw_camera) / sizeof(double))
     reinterpret_cast<double *>(camLds)[threadIdx.x] = reinterpret_cast<const double *>(&p.cam)[threadIdx.x];
@@ -134,8 +180,26 @@ __global__ __launch_bounds__(64 * (NW + 1)) void traceSequentialSpec(
     ctx.tab.sph = ls;
     ctx.tab.tri = lt;
     ctx.tab.mat = lm;
+    off += static_cast<size_t>(p.nsph) * sizeof(SphereRec) +
+           (static_cast<size_t>(p.ntri) * kTriCompactDoubles + static_cast<size_t>(p.nmat) * kMatDoubles) * sizeof(double);
   }
-  const bool isGenerator = wave == NW; // the last wave only produces the stream
+  // FAN: the first-bounce tables of the two ring slots, and whether this fan-out fits them
+  const size_t fanOff = (off + 127) & ~static_cast<size_t>(127);
+  const bool fanOn = FAN && p.fbU >= 1 && p.fbV >= 1 && p.fbU <= kFanStrata && p.fbV <= kFanStrata;
+  // entry (slot, q, k): stratum k of both axes, from the draws at q (u) and q + 1 (v; not for the block's last position)
+  auto fanEntry = [&](unsigned slotIdx, int q, int k) {
+    const double *cn = reinterpret_cast<const double *>(ldsRaw + (slotIdx ? kRingStride : 0u));
+    double *e = reinterpret_cast<double *>(ldsRaw + fanOff + (slotIdx ? kFanSlotBytes : 0)) + q * kFanEntryDoubles;
+    double u, v;
+    stratify(p, k, k, cn[q], cn[q + 1], p.invU, p.invV, u, v);
+    const double theta = (2 * kPi) * u; // hemisphereSample(), src/math/Samples.cpp:21-30
+    double sn, cs;
+    sinCos<true>(theta, sn, cs);
+    e[2 * k] = cs, e[2 * k + 1] = sn;
+    if (q + 1 < kMtDoubles) e[2 * kFanStrata + 2 * k] = sqrtPos(v), e[2 * kFanStrata + 2 * k + 1] = sqrtPos(1 - v);
+  };
+  const bool isGenerator = wave >= NW; // the last wave(s) only produce the stream (and its tables)
+  const int gen = wave - NW;           // generator waves: 0 generates the draws and folds the samples
   if (!isGenerator) ctx.loadPrimitives();
 
   // ---- the stream: resume (or start) this pass's generator ring ----
@@ -146,7 +210,7 @@ __global__ __launch_bounds__(64 * (NW + 1)) void traceSequentialSpec(
   int fQ = 0;        // ... and position in it
   if (p.firstBand) {
     __syncthreads();
-    if (isGenerator) {
+    if (isGenerator && gen == 0) {
       specGenerateBlock(mt, ring, 0, lane);           // block 0
       specGenerateBlock(mt, ring, kRingStride, lane); // block 1 (completes block 0's overlap)
     }
@@ -165,16 +229,84 @@ __global__ __launch_bounds__(64 * (NW + 1)) void traceSequentialSpec(
     }
   }
   __syncthreads();
+  if (FAN) { // both slots' first-bounce tables, by everybody; generation 1 of each slot is complete
+    if (fanOn)
+      for (int t = threadIdx.x; t < 2 * kMtDoubles * kFanStrata; t += kBlock) {
+        const int slotIdx = t >= kMtDoubles * kFanStrata, r = t - slotIdx * kMtDoubles * kFanStrata;
+        fanEntry(slotIdx, r >> 2, r & 3);
+      }
+    if (threadIdx.x < 2) genCmd[4 + threadIdx.x] = kGens;
+    __syncthreads();
+  }
 
   // ---- the generator wave: serves one command per workgroup barrier until told to exit ----
   if (isGenerator) {
+    // the sample of the pixel whose rounds are being reported, summed in sub-sample order
+    d3 acc = mk(0, 0, 0), finE = mk(0, 0, 0), finD = mk(0, 0, 0);
+    uint32_t finPixel = 0, finPick = 0, finPickBase = 1;
+    unsigned long long finRays = 0; // rays of the committed sub-samples (the tracing waves count the primary rays)
+    double *myStageG = stage + static_cast<size_t>(pass) * p.pixCount * 3;
+    uint32_t fanPending = 0; // FAN: the slot command of the barrier before (its draws are complete by now)
     for (unsigned k = 0;; ++k) {
       ldsBarrier();
-      const uint32_t cmd = genCmd[k & 1];
+      const uint32_t word = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(genCmd[k & 1])));
+      const uint32_t cmd = word & 3u;
+      if (gen == 0 && (word & kFinValid)) {
+        if (word & kFinFirst) {
+          const PixFin &f = pixFin[(word >> kFinRecShift) & 3u];
+          finE = mk(f.e[0], f.e[1], f.e[2]), finD = mk(f.dif[0], f.dif[1], f.dif[2]);
+          finPixel = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(f.pixel)));
+          finPick = f.pick0, finPickBase = 1;
+          acc = mk(0, 0, 0);
+        }
+        const SpecResult *slot = results + ((word >> kFinSetShift) & 3u) * kSpecWaves;
+        auto add = [&](int wv) {
+          const SpecResult &r = slot[wv];
+          const d3 child = mk(r.L[0], r.L[1], r.L[2]);
+          const int meta = __builtin_amdgcn_readfirstlane(r.meta);
+          acc = acc + ((meta & 0x100) ? finE + child : finE + finD * child);
+          finRays += static_cast<unsigned>(meta >> 16);
+          if (PICKS) {
+            const uint32_t pw = static_cast<uint32_t>(r.pad);
+            finPick += finPickBase * (pw & 0xffffu) + (pw >> 16);
+            finPickBase += static_cast<uint32_t>(meta) >> 16;
+          }
+        };
+        add(0);
+        if (word & kFinOk1) add(1);
+        if (word & kFinOk2a) add(2);
+        if (word & kFinOk3) add(3);
+        if (word & kFinOk2b) add(2);
+        if (word & kFinLast) {
+          const d3 L = acc * p.invFirstBounce;
+          if (lane == 0) {
+            myStageG[finPixel * 3 + 0] = L.x;
+            myStageG[finPixel * 3 + 1] = L.y;
+            myStageG[finPixel * 3 + 2] = L.z;
+            if (PICKS && picks) picks[static_cast<size_t>(pass) * p.npix + p.pixBegin + finPixel] = finPick;
+          }
+        }
+      }
       if (cmd == kGenExit) break;
-      if (cmd == kGenSlot0) specGenerateBlock(mt, ring, 0, lane);
-      if (cmd == kGenSlot1) specGenerateBlock(mt, ring, kRingStride, lane);
+      if (FAN && fanPending != 0) {
+        // this wave's quarter of the new block's first-bounce table: 78 positions x 4 strata
+        const unsigned slotIdx = fanPending == kGenSlot1 ? 1u : 0u;
+        if (fanOn)
+          for (int t = lane; t < (kMtDoubles / kSpecGens) * kFanStrata; t += 64)
+            fanEntry(slotIdx, gen * (kMtDoubles / kSpecGens) + (t >> 2), t & 3);
+        waveSync();
+        if (lane == 0) {
+          typedef uint32_t __attribute__((address_space(3))) LdsU32;
+          (void)__hip_atomic_fetch_add((LdsU32 *)(genCmd + 4 + slotIdx), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        fanPending = 0;
+      }
+      if (cmd == kGenSlot0 || cmd == kGenSlot1) {
+        if (FAN) fanPending = cmd;
+        if (gen == 0) specGenerateBlock(mt, ring, cmd == kGenSlot1 ? kRingStride : 0u, lane);
+      }
     }
+    if (gen == 0 && lane == 0 && rayCounters) atomicAdd(rayCounters + pass, finRays);
   } else {
   // Stream bookkeeping of the tracing waves (identical in all of them).  When the frontier
   // enters the other slot, the slot it left is handed to the generator wave with the next
@@ -186,10 +318,12 @@ __global__ __launch_bounds__(64 * (NW + 1)) void traceSequentialSpec(
   int genState = 0;
   unsigned genSlot = 0;
   const int ahead = 12 * (p.maxDepth > 0 ? p.maxDepth : 1) + 8;
+  uint32_t finInfo = 0; // the committed round not yet reported to the generator (kFin* bits; 0: none)
   auto roundBarrier = [&](uint32_t exitCmd) {
     if (threadIdx.x == 0)
       reinterpret_cast<uint32_t *>(ldsRaw + kGenCmdOffset)[barriers & 1] =
-          exitCmd ? exitCmd : (genState == 1 ? (genSlot ? kGenSlot1 : kGenSlot0) : kGenNone);
+          (exitCmd ? exitCmd : (genState == 1 ? (genSlot ? kGenSlot1 : kGenSlot0) : kGenNone)) | finInfo;
+    finInfo = 0;
     ldsBarrier();
     ++barriers;
     genState = genState == 1 ? 2 : 0;
@@ -197,11 +331,15 @@ __global__ __launch_bounds__(64 * (NW + 1)) void traceSequentialSpec(
   auto ensureAhead = [&]() {
     while (genState != 0 && fQ + ahead >= kMtDoubles) roundBarrier(0);
   };
+  uint32_t fanExp0 = kGens, fanExp1 = kGens; // FAN: the slots' table counters once their latest generation is complete
   auto advanceFrontier = [&](int n) { // n < kMtDoubles
     const int np = fQ + n;
     if (np >= kMtDoubles) {
       genSlot = fOff; // the slot left behind takes the block after the next
       genState = 1;
+      if (FAN) {
+        if (fOff) fanExp1 += kGens; else fanExp0 += kGens;
+      }
       fQ = np - kMtDoubles;
       fOff ^= kRingStride;
     } else {
@@ -231,13 +369,14 @@ __global__ __launch_bounds__(64 * (NW + 1)) void traceSequentialSpec(
 #if PTW_PROFILE_PHASES
   unsigned long long stRounds = 0, stCommits = 0, stWork = 0, stWait = 0, stCommit = 0, stPrimary = 0;
   unsigned long long stOk1 = 0, stOk2a = 0, stOk3 = 0, stOk2b = 0, stIdle = 0;
-  unsigned long long stPrimTried = 0, stPrimTaken = 0, stCommitHist[5] = {0, 0, 0, 0, 0};
+  unsigned long long stPrimTried = 0, stPrimTaken = 0, stCommitHist[5] = {0, 0, 0, 0, 0}, stTasks = 0, stFanHit = 0;
   const unsigned long long stT0 = __builtin_amdgcn_s_memtime();
 #endif
 
   // CROSS: the wave (1..3) whose record holds THIS pixel's camera ray and first hit, traced during the previous
   // pixel's last round at the stream position that pixel really ended at; 0 = none (trace it now)
   int primWave = 0;
+  int finRec = 0; // the PixFin record of the latest pixel with a fan-out
   int px = static_cast<int>(p.pixBegin % static_cast<uint32_t>(w));
   int py = static_cast<int>(p.pixBegin / static_cast<uint32_t>(w));
   for (uint32_t i = 0; i < p.pixCount; ++i) {
@@ -248,9 +387,9 @@ __global__ __launch_bounds__(64 * (NW + 1)) void traceSequentialSpec(
     const int camDraws = lens ? 4 : 2;
     d3 o, d;
     int sampleDraws = camDraws;
-    uint32_t pickSum = 0, pickBase = 1; // the sample's pick checksum; intersect() calls committed so far
+    uint32_t pickSum = 0; // the pick checksum's term of the primary ray (the generator wave adds the fan-out's)
     d3 L = mk(0, 0, 0);
-    bool traced = false;
+    bool traced = false, genSums = false;
     HitKey k0;
     k0.t = kInf, k0.idx = kMiss, k0.det = 0;
 #if PTW_PROFILE_PHASES
@@ -308,8 +447,19 @@ __global__ __launch_bounds__(64 * (NW + 1)) void traceSequentialSpec(
       } else {
         d3 result = mk(0, 0, 0);
         int j = 0;
+        if (nSub > 0) {
+          // the generator wave sums this pixel's fan-out: what it needs, before the first round's barrier
+          genSums = true;
+          finRec = finRec == kSpecPixFins - 1 ? 0 : finRec + 1;
+          if (threadIdx.x == 0) {
+            PixFin &f = pixFin[finRec];
+            f.e[0] = first.emission.x, f.e[1] = first.emission.y, f.e[2] = first.emission.z;
+            f.dif[0] = first.diffuse.x, f.dif[1] = first.diffuse.y, f.dif[2] = first.diffuse.z;
+            f.pixel = i, f.pick0 = pickSum;
+          }
+        }
+        if (hist & 0x0820820820820820ull) hist = (hist >> 1) & 0x07df7df7df7df7dfull; // (a field never passes 63)
         if (hist != 0) { // refresh the guesses once per sample
-          if (hist & 0x0820820820820820ull) hist = (hist >> 1) & 0x07df7df7df7df7dfull;
           int best = 0, bestN = -1, second = 0, secondN = 0;
 #pragma unroll
           for (int f = 1; f <= 9; ++f) {
@@ -348,21 +498,48 @@ __global__ __launch_bounds__(64 * (NW + 1)) void traceSequentialSpec(
             ctx.pickReset();
             // sub-sample index -> stratum (uS, vS) -> stratified (u, v); ONE decision for the
             // usual power-of-two fan-outs (shift / mask / multiply), the general case apart
+            int uS, vS;
+            if (fastFan) {
+              uS = myIdx >> vShift, vS = myIdx & vMask;
+            } else {
+              uS = myIdx / p.fbV, vS = myIdx - uS * p.fbV;
+            }
+            // FAN: the table entry of this position and stratum, fetched with the draws (one wait); it counts when the
+            // slot's latest generation is complete and the position is not the block's last
+            const unsigned rOff = ctx.ringOff;
+            const int q0 = ctx.pos;
+            double fc = 0, fs = 0, fr = 0, fz = 0;
+            uint32_t fanCnt = 0;
+            if (FAN && fanOn) {
+              const double *e = reinterpret_cast<const double *>(ldsRaw + fanOff + (rOff ? kFanSlotBytes : 0)) + q0 * kFanEntryDoubles;
+              fc = e[2 * uS], fs = e[2 * uS + 1], fr = e[2 * kFanStrata + 2 * vS], fz = e[2 * kFanStrata + 2 * vS + 1];
+              fanCnt = reinterpret_cast<const uint32_t *>(ldsRaw + kGenCmdOffset)[4 + (rOff ? 1 : 0)];
+            }
             double xu, xv, pd;
             ctx.draw3(xu, xv, pd);
-            double u, v;
-            if (fastFan) {
-              const int uS = myIdx >> vShift, vS = myIdx & vMask;
-              u = (static_cast<double>(uS) + xu) * invU;
-              v = (static_cast<double>(vS) + xv) * invV;
-            } else {
-              const int uS = myIdx / p.fbV, vS = myIdx - uS * p.fbV;
-              const double ur = static_cast<double>(uS) + xu, vr = static_cast<double>(vS) + xv;
-              u = p.uPow2 ? ur * invU : ur / static_cast<double>(p.fbU);
-              v = p.vPow2 ? vr * invV : vr / static_cast<double>(p.fbV);
-            }
+            if (FAN) asm volatile("" : "+v"(fc), "+v"(fr), "+v"(fanCnt), "+v"(xu), "+v"(pd)); // one wait for everything
+            const bool fanHit = FAN && fanOn &&
+                                uniformBool((fanCnt == (rOff ? fanExp1 : fanExp0)) & (q0 != kMtDoubles - 1) & !(pd < first.reflectivity));
+#if PTW_PROFILE_PHASES
+            stTasks++, stFanHit += fanHit;
+#endif
             d3 nd;
-            const bool refl = scatter(ctx, first, d, u, v, pd, nd);
+            bool refl;
+            if (fanHit) { // hemisphereSample() from the table: the same (c r, s r, sqrt(1 - v))
+              nd = normalisedNearUnit(transform(first.basis, mk(fc * fr, fs * fr, fz)));
+              refl = false;
+            } else {
+              double u, v;
+              if (fastFan) {
+                u = (static_cast<double>(uS) + xu) * invU;
+                v = (static_cast<double>(vS) + xv) * invV;
+              } else {
+                const double ur = static_cast<double>(uS) + xu, vr = static_cast<double>(vS) + xv;
+                u = p.uPow2 ? ur * invU : ur / static_cast<double>(p.fbU);
+                v = p.vPow2 ? vr * invV : vr / static_cast<double>(p.fbV);
+              }
+              refl = scatter(ctx, first, d, u, v, pd, nd);
+            }
             const d3 child = ctx.chainHot(p, first.pos, nd);
             mine.L[0] = child.x, mine.L[1] = child.y, mine.L[2] = child.z;
             mine.meta = static_cast<int>(ctx.words >> 1) | (refl ? 0x100 : 0) |
@@ -426,47 +603,19 @@ __global__ __launch_bounds__(64 * (NW + 1)) void traceSequentialSpec(
           const int ok2b = ok3 & lt(j + 3, nSub) & ~w2Second & eq(d2, cur2);
           const int cur = cur2 + (c2 & ok2b);
           const int nIdx = 1 - two - ok3 - ok2b;
-          // histogram of the committed counts (6-bit fields indexed by count / 3)
-          auto note = [&](int on, int c) {
-            hist += (1ull << (6 * ((c * 11) >> 5))) & static_cast<unsigned long long>(static_cast<long long>(on));
-          };
-          note(-1, c0);
-          note(ok1, c1);
-          note(ok2a, c2);
-          note(ok3, c3);
-          note(ok2b, c2);
-          raysTotal += static_cast<unsigned>(meta0 >> 16) + (static_cast<unsigned>(meta1 >> 16) & ok1) +
-                       (static_cast<unsigned>(meta2 >> 16) & (ok2a | ok2b)) +
-                       (static_cast<unsigned>(meta3 >> 16) & ok3);
-          if (PICKS && picks && wave == 0) { // the committed sub-samples' picks, in sub-sample order
-            auto addPicks = [&](int wv, int meta) {
-              const uint32_t pw = static_cast<uint32_t>(slot[wv].pad);
-              pickSum += pickBase * (pw & 0xffffu) + (pw >> 16);
-              pickBase += static_cast<uint32_t>(meta) >> 16;
-            };
-            addPicks(0, meta0);
-            if (ok1) addPicks(1, meta1);
-            if (ok2a) addPicks(2, meta2);
-            if (ok3) addPicks(3, meta3);
-            if (ok2b) addPicks(2, meta2);
-          }
-          if (wave == 0) { // only the wave that stores the sample needs the radiance
-            auto add = [&](int wv, int meta) {
-              const SpecResult &r = slot[wv];
-              const d3 child = mk(r.L[0], r.L[1], r.L[2]);
-              result = result + ((meta & 0x100) ? first.emission + child
-                                                : first.emission + first.diffuse * child);
-            };
-            add(0, meta0);
-            if (ok1) add(1, meta1);
-            if (ok2a) add(2, meta2);
-            if (ok3) add(3, meta3);
-            if (ok2b) add(2, meta2);
-          }
+          // Histogram of the counts (6-bit fields indexed by count / 3): the FRONTIER's own count only - every round
+          // has exactly one, it is as good a sample of the distribution as the counts of all committed sub-samples,
+          // and four notes fewer are forty scalar instructions fewer on every wave's path between two rounds.
+          hist += 1ull << (6 * ((c0 * 11) >> 5));
+          // What the generator wave needs to fold this round's committed results (it counts their rays and picks too)
+          finInfo = kFinValid | (static_cast<uint32_t>(ok1) & kFinOk1) | (static_cast<uint32_t>(ok2a) & kFinOk2a) |
+                    (static_cast<uint32_t>(ok3) & kFinOk3) | (static_cast<uint32_t>(ok2b) & kFinOk2b) |
+                    (static_cast<uint32_t>(parity) << kFinSetShift) | (j == 0 ? kFinFirst : 0u) |
+                    (static_cast<uint32_t>(finRec) << kFinRecShift) | (j + nIdx >= nSub ? kFinLast : 0u);
           if (CROSS) lastJ = j, lastCur = cur, lastD1 = d1, lastD2 = d2, lastD3 = d3v, lastOne = oneMode ? -1 : 0;
           j += nIdx;
           sampleDraws += cur;
-          parity ^= 1;
+          parity = parity == kSpecResultSets - 1 ? 0 : parity + 1;
           advanceFrontier(cur);
 #if PTW_PROFILE_PHASES
           stRounds++, stCommits += nIdx;
@@ -491,11 +640,13 @@ __global__ __launch_bounds__(64 * (NW + 1)) void traceSequentialSpec(
       }
     }
     if (threadIdx.x == 0) {
-      myStage[i * 3 + 0] = L.x;
-      myStage[i * 3 + 1] = L.y;
-      myStage[i * 3 + 2] = L.z;
+      if (!genSums) { // (else the generator wave stores the sample and its picks)
+        myStage[i * 3 + 0] = L.x;
+        myStage[i * 3 + 1] = L.y;
+        myStage[i * 3 + 2] = L.z;
+        if (PICKS && picks) picks[static_cast<size_t>(pass) * p.npix + pix] = pickSum;
+      }
       if (words) words[static_cast<size_t>(pass) * p.npix + pix] = 2u * static_cast<unsigned>(sampleDraws);
-      if (PICKS && picks) picks[static_cast<size_t>(pass) * p.npix + pix] = pickSum;
     }
     px = pxNext, py = pyNext;
   }
@@ -516,13 +667,15 @@ __global__ __launch_bounds__(64 * (NW + 1)) void traceSequentialSpec(
            "primary ray traced ahead by this wave in %.3f rounds per pixel, pixels that started from such a record %.3f\n",
            wave, (double)stCommitHist[1] / stRounds, (double)stCommitHist[2] / stRounds, (double)stCommitHist[3] / stRounds,
            (double)stCommitHist[4] / stRounds, stPrimTried / n, stPrimTaken / n);
+    printf("SPEC wave %d: sub-sample tasks %.2f per pixel, first-bounce scatter taken from the table in %.4f of them\n", wave,
+           stTasks / n, stTasks ? (double)stFanHit / stTasks : 0.0);
   }
 #endif
   if (threadIdx.x == 0) {
     myPark[2 * kRingCanonDoubles] = fOff ? 1.0 : 0.0;
     myPark[2 * kRingCanonDoubles + 1] = static_cast<double>(fQ);
-    if (rayCounters) rayCounters[pass] += raysTotal;
   }
+  if (threadIdx.x == 0 && rayCounters) atomicAdd(rayCounters + pass, raysTotal); // (the primary rays; the generator adds the rest)
   } // tracing waves
   // ---- park the stream for the next band ----
   __syncthreads();
@@ -547,17 +700,21 @@ hipError_t launchSeqSpec(const TraceParams &p, const TraceBuffers &b, const Laun
   const bool ahead = hints.seqSmallKernel != 3, two = hints.seqSmallKernel == 4;
   setVariant(two ? "traceSequentialSpec<2 waves>" : ahead ? "traceSequentialSpec" : "traceSequentialSpec<no cross-pixel candidate>");
   if (hints.dryRun) return hipSuccess;
-  const size_t lds = specLdsBytes(p.ntri, p.nmat, p.nsph, !two);
+  // the first-bounce tables (FAN): the four-wave form, while a workgroup's LDS holds them
+  const bool fan = !two && specLdsBytes(p.ntri, p.nmat, p.nsph, true, true) <= kSpecLdsLimit;
+  const size_t lds = specLdsBytes(p.ntri, p.nmat, p.nsph, !two, fan);
   auto kernel = two ? (b.picks ? traceSequentialSpec<true, true, 2> : traceSequentialSpec<false, true, 2>)
-                    : b.picks ? (ahead ? traceSequentialSpec<true, true> : traceSequentialSpec<true, false>)
-                              : (ahead ? traceSequentialSpec<false, true> : traceSequentialSpec<false, false>);
+                : fan ? (b.picks ? (ahead ? traceSequentialSpec<true, true, kSpecWaves, true> : traceSequentialSpec<true, false, kSpecWaves, true>)
+                                 : (ahead ? traceSequentialSpec<false, true, kSpecWaves, true> : traceSequentialSpec<false, false, kSpecWaves, true>))
+                : b.picks ? (ahead ? traceSequentialSpec<true, true> : traceSequentialSpec<true, false>)
+                          : (ahead ? traceSequentialSpec<false, true> : traceSequentialSpec<false, false>);
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds));
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kernel, dim3(p.npass), dim3(64 * ((two ? 2 : kSpecWaves) + 1)), lds, stream, p,
+  hipLaunchKernelGGL(kernel, dim3(p.npass), dim3(64 * ((two ? 2 : kSpecWaves) + (fan ? kSpecGens : 1))), lds, stream, p,
                      b.triGeom, b.spheres, b.triCompact, b.matTable, b.mtState, b.specState, b.stage,
                      b.words, b.rays, b.picks);
   return hipGetLastError();
