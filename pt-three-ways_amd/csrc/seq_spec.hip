@@ -72,25 +72,7 @@ constexpr uint32_t kFinValid = 4, kFinOk1 = 8, kFinOk2a = 16, kFinOk3 = 32, kFin
                    kFinFirst = 512, kFinRecShift = 10, kFinLast = 4096;
 constexpr int kSpecPixFins = 3;
 
-// FAN (round 6, the four-wave form): the first-bounce scatter of a sub-sample - stratify, one sincos, two square roots
-// - depends on the draws at its stream position and on its stratum only, like the deeper levels' local directions
-// (SeqShared::hemi).  For fan-outs of at most 4 x 4 strata the generator side computes, per position q of a block and
-// stratum k of each axis, (cos, sin)(2 pi u_k(canon[q])) and (sqrt v_k, sqrt(1 - v_k))(canon[q + 1]) with the very
-// functions hemisphereSample() calls - 16 doubles per position, 39 KB per block - so that a tracing wave's task starts
-// with two 16-byte LDS reads and two multiplications where it evaluated ~110 vector instructions.  FOUR generator
-// waves, one per SIMD, build a quarter each in the issue slots their tracing wave leaves empty, one barrier after the
-// block's draws exist; a counter per slot says when a generation is complete, and a task whose table is not (or whose
-// position is the block's last: its v needs the next block) evaluates the scatter itself as before - same values.
-constexpr int kFanStrata = 4;
-constexpr int kFanEntryDoubles = 4 * kFanStrata;
-constexpr size_t kFanSlotBytes = static_cast<size_t>(kMtDoubles) * kFanEntryDoubles * sizeof(double);
-constexpr int kSpecGens = 4; // generator waves of the FAN form
-#ifndef PTW_SPEC_FAN
-#define PTW_SPEC_FAN 1
-#endif
-constexpr size_t kSpecLdsLimit = PTW_SPEC_FAN ? 160 * 1024 : 0; // a gfx950 workgroup's LDS (0: A/B build without the tables)
-
-__host__ __device__ inline size_t specLdsBytes(uint32_t ntri, uint32_t nmat, uint32_t nsph, bool wholeCu = true, bool fan = false) {
+__host__ __device__ inline size_t specLdsBytes(uint32_t ntri, uint32_t nmat, uint32_t nsph, bool wholeCu = true) {
   size_t n = 2 * kRingStride;                          // the ring
   n += kMtWords * sizeof(uint32_t);                    // raw generator state
   n += kSpecResultSets * kSpecWaves * sizeof(SpecResult); // results: three sets in turn
@@ -103,7 +85,6 @@ __host__ __device__ inline size_t specLdsBytes(uint32_t ntri, uint32_t nmat, uin
   // more than half of a CU's 160 KB: one workgroup per CU, so its four waves get a SIMD each.  (Not for the
   // two-wave form: two of its workgroups - three waves each - share a CU, which is what fills the SIMDs when there
   // are two passes per CU.)
-  if (fan) n = ((n + 127) & ~static_cast<size_t>(127)) + 2 * kFanSlotBytes;
   const size_t floor = wholeCu ? 84 * 1024 : 0;
   return n < floor ? floor : n;
 }
@@ -112,17 +93,15 @@ __host__ __device__ inline size_t specLdsBytes(uint32_t ntri, uint32_t nmat, uin
 // frontier plus ONE candidate - sub-sample j+1 assuming m1 - and two workgroups per CU: with between one and two
 // passes per CU it fills the SIMDs that one wave per pass leaves empty (1.5 commits per round instead of 2.04; the
 // LDS areas keep their four-wave layout, slots 2 and 3 are never written and never read).
-template <bool PICKS, bool CROSS, int NW = kSpecWaves, bool FAN = false>
-__global__ __launch_bounds__(64 * (NW + (FAN ? kSpecGens : 1))) void traceSequentialSpec(
+template <bool PICKS, bool CROSS, int NW = kSpecWaves>
+__global__ __launch_bounds__(64 * (NW + 1)) void traceSequentialSpec(
     const TraceParams p, const double *__restrict__ triGeom, const SphereRec *__restrict__ spheres,
     const double *__restrict__ triCompact, const double *__restrict__ matTable,
     uint32_t *__restrict__ mtState, double *__restrict__ specState, double *__restrict__ stage,
     uint32_t *__restrict__ words, unsigned long long *__restrict__ rayCounters, uint32_t *__restrict__ picks) {
   extern __shared__ __attribute__((aligned(64))) unsigned char ldsRaw[];
   static_assert(NW == 2 || NW == kSpecWaves, "two or four tracing waves");
-  static_assert(!FAN || NW == kSpecWaves, "the first-bounce tables exist for the four-wave form");
-  constexpr int kGens = FAN ? kSpecGens : 1;
-  constexpr int kBlock = 64 * (NW + kGens);
+  constexpr int kBlock = 64 * (NW + 1);
   constexpr int has23 = NW > 2 ? -1 : 0; // (all-ones / zero mask: waves 2 and 3 exist)
   char *ring = reinterpret_cast<char *>(ldsRaw);
   uint32_t *mt = reinterpret_cast<uint32_t *>(ldsRaw + 2 * kRingStride);
@@ -180,26 +159,8 @@ __global__ __launch_bounds__(64 * (NW + (FAN ? kSpecGens : 1))) void traceSequen
     ctx.tab.sph = ls;
     ctx.tab.tri = lt;
     ctx.tab.mat = lm;
-    off += static_cast<size_t>(p.nsph) * sizeof(SphereRec) +
-           (static_cast<size_t>(p.ntri) * kTriCompactDoubles + static_cast<size_t>(p.nmat) * kMatDoubles) * sizeof(double);
   }
-  // FAN: the first-bounce tables of the two ring slots, and whether this fan-out fits them
-  const size_t fanOff = (off + 127) & ~static_cast<size_t>(127);
-  const bool fanOn = FAN && p.fbU >= 1 && p.fbV >= 1 && p.fbU <= kFanStrata && p.fbV <= kFanStrata;
-  // entry (slot, q, k): stratum k of both axes, from the draws at q (u) and q + 1 (v; not for the block's last position)
-  auto fanEntry = [&](unsigned slotIdx, int q, int k) {
-    const double *cn = reinterpret_cast<const double *>(ldsRaw + (slotIdx ? kRingStride : 0u));
-    double *e = reinterpret_cast<double *>(ldsRaw + fanOff + (slotIdx ? kFanSlotBytes : 0)) + q * kFanEntryDoubles;
-    double u, v;
-    stratify(p, k, k, cn[q], cn[q + 1], p.invU, p.invV, u, v);
-    const double theta = (2 * kPi) * u; // hemisphereSample(), src/math/Samples.cpp:21-30
-    double sn, cs;
-    sinCos<true>(theta, sn, cs);
-    e[2 * k] = cs, e[2 * k + 1] = sn;
-    if (q + 1 < kMtDoubles) e[2 * kFanStrata + 2 * k] = sqrtPos(v), e[2 * kFanStrata + 2 * k + 1] = sqrtPos(1 - v);
-  };
-  const bool isGenerator = wave >= NW; // the last wave(s) only produce the stream (and its tables)
-  const int gen = wave - NW;           // generator waves: 0 generates the draws and folds the samples
+  const bool isGenerator = wave == NW; // the last wave only produces the stream
   if (!isGenerator) ctx.loadPrimitives();
 
   // ---- the stream: resume (or start) this pass's generator ring ----
@@ -210,7 +171,7 @@ __global__ __launch_bounds__(64 * (NW + (FAN ? kSpecGens : 1))) void traceSequen
   int fQ = 0;        // ... and position in it
   if (p.firstBand) {
     __syncthreads();
-    if (isGenerator && gen == 0) {
+    if (isGenerator) {
       specGenerateBlock(mt, ring, 0, lane);           // block 0
       specGenerateBlock(mt, ring, kRingStride, lane); // block 1 (completes block 0's overlap)
     }
@@ -229,15 +190,6 @@ __global__ __launch_bounds__(64 * (NW + (FAN ? kSpecGens : 1))) void traceSequen
     }
   }
   __syncthreads();
-  if (FAN) { // both slots' first-bounce tables, by everybody; generation 1 of each slot is complete
-    if (fanOn)
-      for (int t = threadIdx.x; t < 2 * kMtDoubles * kFanStrata; t += kBlock) {
-        const int slotIdx = t >= kMtDoubles * kFanStrata, r = t - slotIdx * kMtDoubles * kFanStrata;
-        fanEntry(slotIdx, r >> 2, r & 3);
-      }
-    if (threadIdx.x < 2) genCmd[4 + threadIdx.x] = kGens;
-    __syncthreads();
-  }
 
   // ---- the generator wave: serves one command per workgroup barrier until told to exit ----
   if (isGenerator) {
@@ -246,12 +198,11 @@ __global__ __launch_bounds__(64 * (NW + (FAN ? kSpecGens : 1))) void traceSequen
     uint32_t finPixel = 0, finPick = 0, finPickBase = 1;
     unsigned long long finRays = 0; // rays of the committed sub-samples (the tracing waves count the primary rays)
     double *myStageG = stage + static_cast<size_t>(pass) * p.pixCount * 3;
-    uint32_t fanPending = 0; // FAN: the slot command of the barrier before (its draws are complete by now)
     for (unsigned k = 0;; ++k) {
       ldsBarrier();
       const uint32_t word = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(genCmd[k & 1])));
       const uint32_t cmd = word & 3u;
-      if (gen == 0 && (word & kFinValid)) {
+      if (word & kFinValid) {
         if (word & kFinFirst) {
           const PixFin &f = pixFin[(word >> kFinRecShift) & 3u];
           finE = mk(f.e[0], f.e[1], f.e[2]), finD = mk(f.dif[0], f.dif[1], f.dif[2]);
@@ -288,25 +239,10 @@ __global__ __launch_bounds__(64 * (NW + (FAN ? kSpecGens : 1))) void traceSequen
         }
       }
       if (cmd == kGenExit) break;
-      if (FAN && fanPending != 0) {
-        // this wave's quarter of the new block's first-bounce table: 78 positions x 4 strata
-        const unsigned slotIdx = fanPending == kGenSlot1 ? 1u : 0u;
-        if (fanOn)
-          for (int t = lane; t < (kMtDoubles / kSpecGens) * kFanStrata; t += 64)
-            fanEntry(slotIdx, gen * (kMtDoubles / kSpecGens) + (t >> 2), t & 3);
-        waveSync();
-        if (lane == 0) {
-          typedef uint32_t __attribute__((address_space(3))) LdsU32;
-          (void)__hip_atomic_fetch_add((LdsU32 *)(genCmd + 4 + slotIdx), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        fanPending = 0;
-      }
-      if (cmd == kGenSlot0 || cmd == kGenSlot1) {
-        if (FAN) fanPending = cmd;
-        if (gen == 0) specGenerateBlock(mt, ring, cmd == kGenSlot1 ? kRingStride : 0u, lane);
-      }
+      if (cmd == kGenSlot0) specGenerateBlock(mt, ring, 0, lane);
+      if (cmd == kGenSlot1) specGenerateBlock(mt, ring, kRingStride, lane);
     }
-    if (gen == 0 && lane == 0 && rayCounters) atomicAdd(rayCounters + pass, finRays);
+    if (lane == 0 && rayCounters) atomicAdd(rayCounters + pass, finRays);
   } else {
   // Stream bookkeeping of the tracing waves (identical in all of them).  When the frontier
   // enters the other slot, the slot it left is handed to the generator wave with the next
@@ -331,15 +267,11 @@ __global__ __launch_bounds__(64 * (NW + (FAN ? kSpecGens : 1))) void traceSequen
   auto ensureAhead = [&]() {
     while (genState != 0 && fQ + ahead >= kMtDoubles) roundBarrier(0);
   };
-  uint32_t fanExp0 = kGens, fanExp1 = kGens; // FAN: the slots' table counters once their latest generation is complete
   auto advanceFrontier = [&](int n) { // n < kMtDoubles
     const int np = fQ + n;
     if (np >= kMtDoubles) {
       genSlot = fOff; // the slot left behind takes the block after the next
       genState = 1;
-      if (FAN) {
-        if (fOff) fanExp1 += kGens; else fanExp0 += kGens;
-      }
       fQ = np - kMtDoubles;
       fOff ^= kRingStride;
     } else {
@@ -369,7 +301,7 @@ __global__ __launch_bounds__(64 * (NW + (FAN ? kSpecGens : 1))) void traceSequen
 #if PTW_PROFILE_PHASES
   unsigned long long stRounds = 0, stCommits = 0, stWork = 0, stWait = 0, stCommit = 0, stPrimary = 0;
   unsigned long long stOk1 = 0, stOk2a = 0, stOk3 = 0, stOk2b = 0, stIdle = 0;
-  unsigned long long stPrimTried = 0, stPrimTaken = 0, stCommitHist[5] = {0, 0, 0, 0, 0}, stTasks = 0, stFanHit = 0;
+  unsigned long long stPrimTried = 0, stPrimTaken = 0, stCommitHist[5] = {0, 0, 0, 0, 0};
   const unsigned long long stT0 = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -445,6 +377,8 @@ __global__ __launch_bounds__(64 * (NW + (FAN ? kSpecGens : 1))) void traceSequen
       if (p.preview) {
         L = first.diffuse; // Scene.cpp:137-138
       } else {
+        // (`result`: what the tracing waves themselves would store - nothing is ever added to it here, the
+        // generator wave holds the sum; it stays zero, and only a fan-out without sub-samples would store it)
         d3 result = mk(0, 0, 0);
         int j = 0;
         if (nSub > 0) {
@@ -498,48 +432,21 @@ __global__ __launch_bounds__(64 * (NW + (FAN ? kSpecGens : 1))) void traceSequen
             ctx.pickReset();
             // sub-sample index -> stratum (uS, vS) -> stratified (u, v); ONE decision for the
             // usual power-of-two fan-outs (shift / mask / multiply), the general case apart
-            int uS, vS;
-            if (fastFan) {
-              uS = myIdx >> vShift, vS = myIdx & vMask;
-            } else {
-              uS = myIdx / p.fbV, vS = myIdx - uS * p.fbV;
-            }
-            // FAN: the table entry of this position and stratum, fetched with the draws (one wait); it counts when the
-            // slot's latest generation is complete and the position is not the block's last
-            const unsigned rOff = ctx.ringOff;
-            const int q0 = ctx.pos;
-            double fc = 0, fs = 0, fr = 0, fz = 0;
-            uint32_t fanCnt = 0;
-            if (FAN && fanOn) {
-              const double *e = reinterpret_cast<const double *>(ldsRaw + fanOff + (rOff ? kFanSlotBytes : 0)) + q0 * kFanEntryDoubles;
-              fc = e[2 * uS], fs = e[2 * uS + 1], fr = e[2 * kFanStrata + 2 * vS], fz = e[2 * kFanStrata + 2 * vS + 1];
-              fanCnt = reinterpret_cast<const uint32_t *>(ldsRaw + kGenCmdOffset)[4 + (rOff ? 1 : 0)];
-            }
             double xu, xv, pd;
             ctx.draw3(xu, xv, pd);
-            if (FAN) asm volatile("" : "+v"(fc), "+v"(fr), "+v"(fanCnt), "+v"(xu), "+v"(pd)); // one wait for everything
-            const bool fanHit = FAN && fanOn &&
-                                uniformBool((fanCnt == (rOff ? fanExp1 : fanExp0)) & (q0 != kMtDoubles - 1) & !(pd < first.reflectivity));
-#if PTW_PROFILE_PHASES
-            stTasks++, stFanHit += fanHit;
-#endif
-            d3 nd;
-            bool refl;
-            if (fanHit) { // hemisphereSample() from the table: the same (c r, s r, sqrt(1 - v))
-              nd = normalisedNearUnit(transform(first.basis, mk(fc * fr, fs * fr, fz)));
-              refl = false;
+            double u, v;
+            if (fastFan) {
+              const int uS = myIdx >> vShift, vS = myIdx & vMask;
+              u = (static_cast<double>(uS) + xu) * invU;
+              v = (static_cast<double>(vS) + xv) * invV;
             } else {
-              double u, v;
-              if (fastFan) {
-                u = (static_cast<double>(uS) + xu) * invU;
-                v = (static_cast<double>(vS) + xv) * invV;
-              } else {
-                const double ur = static_cast<double>(uS) + xu, vr = static_cast<double>(vS) + xv;
-                u = p.uPow2 ? ur * invU : ur / static_cast<double>(p.fbU);
-                v = p.vPow2 ? vr * invV : vr / static_cast<double>(p.fbV);
-              }
-              refl = scatter(ctx, first, d, u, v, pd, nd);
+              const int uS = myIdx / p.fbV, vS = myIdx - uS * p.fbV;
+              const double ur = static_cast<double>(uS) + xu, vr = static_cast<double>(vS) + xv;
+              u = p.uPow2 ? ur * invU : ur / static_cast<double>(p.fbU);
+              v = p.vPow2 ? vr * invV : vr / static_cast<double>(p.fbV);
             }
+            d3 nd;
+            const bool refl = scatter(ctx, first, d, u, v, pd, nd);
             const d3 child = ctx.chainHot(p, first.pos, nd);
             mine.L[0] = child.x, mine.L[1] = child.y, mine.L[2] = child.z;
             mine.meta = static_cast<int>(ctx.words >> 1) | (refl ? 0x100 : 0) |
@@ -624,6 +531,10 @@ __global__ __launch_bounds__(64 * (NW + (FAN ? kSpecGens : 1))) void traceSequen
           stWork += tW1 - tW0, stWait += tW2 - tW1, stCommit += __builtin_amdgcn_s_memtime() - tW2;
 #endif
         }
+        // (Three multiplications per pixel that no pixel with a fan-out uses - and that stay: where the code of the
+        // round loop lands in memory decides +-1.5 % for waves that have their SIMD to themselves, every taken branch
+        // exposes the fetch of its target, and this form's layout is the fastest of the equivalent ones measured:
+        // LAB.md round 6, profiles/r06o_*, r06r_*.)
         L = result * p.invFirstBounce;
         if (CROSS && i + 1 < p.pixCount) {
           // Did a wave trace the next pixel's primary ray in the last round, and from where the pixel ended?
@@ -667,8 +578,6 @@ __global__ __launch_bounds__(64 * (NW + (FAN ? kSpecGens : 1))) void traceSequen
            "primary ray traced ahead by this wave in %.3f rounds per pixel, pixels that started from such a record %.3f\n",
            wave, (double)stCommitHist[1] / stRounds, (double)stCommitHist[2] / stRounds, (double)stCommitHist[3] / stRounds,
            (double)stCommitHist[4] / stRounds, stPrimTried / n, stPrimTaken / n);
-    printf("SPEC wave %d: sub-sample tasks %.2f per pixel, first-bounce scatter taken from the table in %.4f of them\n", wave,
-           stTasks / n, stTasks ? (double)stFanHit / stTasks : 0.0);
   }
 #endif
   if (threadIdx.x == 0) {
@@ -700,21 +609,17 @@ hipError_t launchSeqSpec(const TraceParams &p, const TraceBuffers &b, const Laun
   const bool ahead = hints.seqSmallKernel != 3, two = hints.seqSmallKernel == 4;
   setVariant(two ? "traceSequentialSpec<2 waves>" : ahead ? "traceSequentialSpec" : "traceSequentialSpec<no cross-pixel candidate>");
   if (hints.dryRun) return hipSuccess;
-  // the first-bounce tables (FAN): the four-wave form, while a workgroup's LDS holds them
-  const bool fan = !two && specLdsBytes(p.ntri, p.nmat, p.nsph, true, true) <= kSpecLdsLimit;
-  const size_t lds = specLdsBytes(p.ntri, p.nmat, p.nsph, !two, fan);
+  const size_t lds = specLdsBytes(p.ntri, p.nmat, p.nsph, !two);
   auto kernel = two ? (b.picks ? traceSequentialSpec<true, true, 2> : traceSequentialSpec<false, true, 2>)
-                : fan ? (b.picks ? (ahead ? traceSequentialSpec<true, true, kSpecWaves, true> : traceSequentialSpec<true, false, kSpecWaves, true>)
-                                 : (ahead ? traceSequentialSpec<false, true, kSpecWaves, true> : traceSequentialSpec<false, false, kSpecWaves, true>))
-                : b.picks ? (ahead ? traceSequentialSpec<true, true> : traceSequentialSpec<true, false>)
-                          : (ahead ? traceSequentialSpec<false, true> : traceSequentialSpec<false, false>);
+                    : b.picks ? (ahead ? traceSequentialSpec<true, true> : traceSequentialSpec<true, false>)
+                              : (ahead ? traceSequentialSpec<false, true> : traceSequentialSpec<false, false>);
   {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds));
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kernel, dim3(p.npass), dim3(64 * ((two ? 2 : kSpecWaves) + (fan ? kSpecGens : 1))), lds, stream, p,
+  hipLaunchKernelGGL(kernel, dim3(p.npass), dim3(64 * ((two ? 2 : kSpecWaves) + 1)), lds, stream, p,
                      b.triGeom, b.spheres, b.triCompact, b.matTable, b.mtState, b.specState, b.stage,
                      b.words, b.rays, b.picks);
   return hipGetLastError();
