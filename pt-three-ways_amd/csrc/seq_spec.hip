@@ -21,15 +21,15 @@ namespace {
 //      wave 2: sub-sample j+1 assuming m2 (the most recent different count) - or, while no second
 //              value has been seen, sub-sample j+3 assuming m1 three times;
 //      wave 3: sub-sample j+2, assuming m1 twice.
-// After a barrier every wave reads all results and commits, in order, as many sub-samples as the
+// After a barrier every wave reads the four counts and commits, in order, as many sub-samples as the
 // assumptions allow (always j; j+1 if a wave started where j really stopped; and so on).  Wrong
 // guesses cost nothing but the energy: the result is the one the serial order defines, bit for bit
-// - each wave accumulates the committed contributions itself, in sub-sample order.
+// - the committed contributions are added in sub-sample order (by the generator wave: see PixFin).
 //
 // For that the stream must be readable ahead of the frontier: the generator output sits in a
 // ring of two blocks (SeqCtx SPEC mode); while the frontier is in one block the next one is
-// already there, and when the frontier crosses into it, wave 0 generates the block after it into
-// the slot that just became free.
+// already there, and when the frontier crosses into it, a fifth wave - the generator - produces the
+// block after it into the slot that just became free.
 // -----------------------------------------------------------------------------------------
 constexpr int kSpecWaves = 4;
 struct alignas(16) SpecResult { // one per wave and result set, in LDS

@@ -29,6 +29,10 @@ pkg = entry.load_package()
 PEAK = 78.6e12
 SIZES = [32, 64, 96, 128, 256, 512, 1000, 2000, 4000, 8000, 32000]
 PASSES = [256, 512, 1024]
+if os.environ.get("SWEEP_SIZES"):      # e.g. SWEEP_SIZES=32,64 SWEEP_PASSES=384,512,768,1024: a part of the table
+    SIZES = [int(x) for x in os.environ["SWEEP_SIZES"].split(",")]
+if os.environ.get("SWEEP_PASSES"):
+    PASSES = [int(x) for x in os.environ["SWEEP_PASSES"].split(",")]
 
 
 def run(scene, cam_of, ntri, passes, policy, debug, extra):
@@ -71,6 +75,7 @@ def neighbours(ntri, passes, policy):
             out.append(("one wave per pass (reg)", dict(seq_small_kernel=1), {}))
         else:
             out.append(("four speculating waves", dict(seq_small_kernel=2), {}))
+            out.append(("two speculating waves", dict(seq_small_kernel=4), {}))
     elif ntri > 128:
         two = passes > 256
         out.append(("one master" if two else "two masters", dict(seq_two_masters=0 if two else 1), {}))
