@@ -65,17 +65,21 @@ __host__ __device__ inline void seqUnitSplit(uint32_t ntri, int nA, int nB, int 
   if (uA < 0) uA = 0;
 }
 
-// Two-master kernels (four workers in two pairs + two master-side workers), scenes from 31 units on -
-// the ones whose tick is the search, not the masters: shares by the wave's PLACE.  Of two workers on one
+// Two-master kernels (four workers in two pairs + two master-side workers), scenes from 12 units on:
+// shares by the wave's PLACE.  Of two workers on one
 // SIMD the arbiter serves the older wave first; measured per triangle (profiles/r04k_*, ce) the younger
 // one is 35-40 % slower and sets the tick, the master-side waves sit in between.  So the younger wave
 // of each pair gets youngPercent (70) of an older / master-side wave's share: ce's 54 units go 10 / 7 /
-// 10 instead of 9 / 9 / 9 (1.975 -> 2.150 Msamples/s, profiles/r04l_*).  Returns false - leave the
-// equal shares - when the scene is smaller, or when an older wave would need more than `cap` or more
-// than ten units (the largest instantiation that does not spill).
+// 10 instead of 9 / 9 / 9 (1.975 -> 2.150 Msamples/s, profiles/r04l_*).  Through round 5 the rule started at
+// 31 units (scenes whose tick is the search); round 6 measured it below (profiles/r06w_*): suzanne's 16 units
+// 3 / 2 / 3 instead of 3 / 3 / 3 +4.9 % (the masters set its tick, and the younger workers are slow there
+// too), closed soups +1.4 % at 16 units, +8 % at 25, nothing at 8.  Returns false - leave the equal shares -
+// when the scene is smaller, or when an older wave would need more than `cap` (the instantiation the equal
+// shares chose: a bigger one costs more than the shares bring) or more than ten units (the largest
+// instantiation that does not spill).
 __host__ __device__ inline bool seqUnitSplitByPlace(uint32_t ntri, int youngPercent, int cap, int &uOld, int &uYoung, int &uMaster) {
   const int U = static_cast<int>((ntri + 63u) / 64u);
-  if (U < 31 || youngPercent <= 0 || youngPercent >= 100) return false;
+  if (U < 12 || youngPercent <= 0 || youngPercent >= 100) return false;
   const int half = (U + 1) / 2;                 // one pair + one master-side wave: uOld + uYoung + uMaster
   const int den = 200 + youngPercent;
   const int y = (half * youngPercent + den / 2) / den;

@@ -252,14 +252,23 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
 }
 
 // The units of 64 triangles per worker wave: older / younger wave of a worker pair, master-side wave.
-// Equal shares (seqUnitSplit); two masters, scenes from 31 units on: shares by the wave's place
-// (seqUnitSplitByPlace).  LaunchHints::seqUnits sets them outright (tests, A/B runs; what does not fit
-// the waves' shares is streamed from memory).
+// Equal shares (seqUnitSplit); two masters, scenes from 12 units on: shares by the wave's place
+// (seqUnitSplitByPlace) - below 31 units only inside the instantiation the equal shares choose (a larger one
+// costs more than the shares bring: profiles/r06w_*).  LaunchHints::seqUnits sets them outright (tests, A/B
+// runs; what does not fit the waves' shares is streamed from memory).
 void seqUnitsFor(uint32_t ntri, int nA, int nB, int cap, const LaunchHints &hints, int &uO, int &uY, int &uM) {
   int uA, uB;
   seqUnitSplit(ntri, nA, nB, 100, cap, uA, uB);
   uO = uY = uA, uM = uB;
-  if (nA == 4 && nB == 2) (void)seqUnitSplitByPlace(ntri, PTW_SEQ_YOUNG_PERCENT, cap, uO, uY, uM);
+  if (nA == 4 && nB == 2) {
+    int capPlace = cap;
+    if ((ntri + 63u) / 64u < 31u) { // the two-master instantiations: 1, 2, 3, 4, 6, 9, 10, 11 slots
+      const int need = uA > uB ? uA : uB;
+      const int inst = need <= 4 ? need : need <= 6 ? 6 : need <= 9 ? 9 : need;
+      if (inst < capPlace) capPlace = inst;
+    }
+    (void)seqUnitSplitByPlace(ntri, PTW_SEQ_YOUNG_PERCENT, capPlace, uO, uY, uM);
+  }
   const int o = hints.seqUnits[0], y = hints.seqUnits[1], m = hints.seqUnits[2];
   if ((o | y | m) != 0 && o >= 0 && y >= 0 && m >= 0 && o <= cap && y <= cap && m <= cap) uO = o, uY = y, uM = m;
 }

@@ -80,7 +80,7 @@ def neighbours(ntri, passes, policy):
         two = passes > 256
         out.append(("one master" if two else "two masters", dict(seq_two_masters=0 if two else 1), {}))
         units = (ntri + 63) // 64
-        if two and units >= 12:
+        if two and units >= 6:
             eq = (units + 5) // 6
             if eq <= 11:
                 out.append((f"equal shares {eq}/{eq}/{eq}", dict(seq_units=(eq, eq, eq)), {}))

@@ -424,3 +424,56 @@ def test_sequential_prefilter_is_refused_for_small_scenes(pkg):
     with pytest.raises(pkg.PtwError) as e:
         pkg.render(scene, cam, pkg.default_params(width=8, height=8, samples_per_pixel=1, seed=1, accel=pkg.ACCEL_PREFILTER))
     assert e.value.status == 8 and "128" in str(e.value)
+
+
+# ---- the speculative kernels' commit / fold path on random fan-outs, depths, scenes and band cuts ----
+# (round 6: the generator wave folds the committed results one barrier late from three result sets, a 64-byte record
+# per pixel travels in three slots in turn; which slots a pixel meets depends on how many rounds it and its
+# neighbours take - one for a 1 x 1 or a closed 2 x 2 fan-out, up to fbU x fbV - and on where a band ends.)
+def _fold_case(i):
+    rng = np.random.default_rng(1000 + i)
+    kind = ("cornell", "example1", "single-sphere", "soup-open", "soup-closed")[i % 5]
+    return dict(kind=kind, fbu=int(rng.integers(1, 6)), fbv=int(rng.integers(1, 6)), depth=int(rng.integers(1, 8)),
+                w=int(rng.integers(3, 14)), h=int(rng.integers(2, 9)), spp=int(rng.integers(1, 7)),
+                ntri=int(rng.integers(1, 65)), nsph=int(rng.integers(0, 4)), seed=int(rng.integers(1, 1 << 20)),
+                budget_kb=(None, 1, 2)[int(rng.integers(0, 3))], small=(2, 4)[i % 2])
+
+
+@pytest.mark.parametrize("i", range(64))
+def test_speculative_kernels_fold_matches_oracle_on_random_shapes(pkg, ob, monkeypatch, i):
+    import test_gpu_round3 as r3
+    c = _fold_case(i)
+    if c["budget_kb"]:
+        monkeypatch.setenv("PTW_STAGE_BUDGET_KB", str(c["budget_kb"]))
+    w, h = c["w"], c["h"]
+    if c["budget_kb"]:
+        w, h = max(w, 12), max(h, 10)   # (a band is at least 64 pixels: several bands need a frame of a few)
+    if c["kind"].startswith("soup"):
+        scene, cam = r3._soup(pkg, c["ntri"], c["nsph"], seed=c["seed"], w=w, h=h)
+        if c["kind"] == "soup-open":
+            scene = pkg.Scene()
+            rng = np.random.default_rng(c["seed"])
+            mats = [pkg.material("diffuse", rng.uniform(0.2, 0.9, 3)), pkg.material("light", rng.uniform(0.5, 3.0, 3)),
+                    pkg.material("reflective", rng.uniform(0.2, 0.9, 3), 0.5, 4.0)]
+            for k in range(c["ntri"]):
+                ctr = rng.uniform(-3, 3, 3)
+                v = ctr + rng.uniform(-1.5, 1.5, (3, 3))
+                scene.add_triangle(v[0], v[1], v[2], mats[k % 3])
+            for k in range(c["nsph"]):
+                scene.add_sphere(rng.uniform(-3, 3, 3), rng.uniform(0.2, 0.9), mats[(k + 1) % 3])
+            scene.set_environment_colour((0.3, 0.2, 0.1))
+    else:
+        scene = pkg.Scene()
+        cam = scene.build_named(c["kind"], w, h)
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=c["spp"], seed=c["seed"], max_depth=c["depth"],
+                                first_bounce_u=c["fbu"], first_bounce_v=c["fbv"])
+    ref_rgb, ref_cnt, ref_words, ref_picks = ob.oracle_render_picks(scene.view(), cam, params, threads=4)
+    name = {2: "traceSequentialSpec", 4: "traceSequentialSpec<2 waves>"}[c["small"]]
+    rgb, cnt, words, variant, launches, picks = r3._render_with_stats(pkg, scene, cam, params, picks=True, seq_small_kernel=c["small"])
+    assert variant == name, (variant, c)
+    if c["budget_kb"]:
+        assert launches > 1, (launches, c)
+    assert np.array_equal(cnt, ref_cnt), c
+    assert np.array_equal(words, ref_words), c
+    assert np.array_equal(picks, ref_picks), c
+    assert rel_err(rgb, ref_rgb) < TOL, c

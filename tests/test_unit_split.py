@@ -38,21 +38,24 @@ PROGRAM = textwrap.dedent(r"""
       if (uA != 9 || uB != 9) { std::printf("ce %d %d\n", uA, uB); return 1; }
       // round 4: shares by the wave's place (two-master kernels, large scenes)
       for (unsigned ntri = 129; ntri <= 6000; ntri += 7)
-        for (int cap : {6, 9, 10, 11}) {
+        for (int cap : {2, 3, 4, 6, 9, 10, 11}) {
           int o = -1, y = -1, m = -1;
           const int U = (ntri + 63) / 64;
           if (!ptw::seqUnitSplitByPlace(ntri, 70, cap, o, y, m)) {
             if (o != -1 || y != -1 || m != -1) { std::printf("outputs touched on refusal %u\n", ntri); return 1; }
             continue;
           }
-          if (U < 31 || o > cap || o > 10 || m != o || y > o || y < 1) { std::printf("by place: ntri %u cap %d -> %d %d %d\n", ntri, cap, o, y, m); return 1; }
+          if (U < 12 || o > cap || o > 10 || m != o || y > o || y < 1) { std::printf("by place: ntri %u cap %d -> %d %d %d\n", ntri, cap, o, y, m); return 1; }
           if (2 * (o + y + m) < U) { std::printf("by place loses triangles: ntri %u -> %d %d %d for %d\n", ntri, o, y, m, U); return 1; }
           if (2 * (o + y + m) - U > 5) { std::printf("by place wasteful: ntri %u -> %d %d %d for %d\n", ntri, o, y, m, U); return 1; }
           ++checked;
         }
       int o, y, m;
       if (!ptw::seqUnitSplitByPlace(3442, 70, 11, o, y, m) || o != 10 || y != 7 || m != 10) { std::printf("ce by place %d %d %d\n", o, y, m); return 1; }
-      if (ptw::seqUnitSplitByPlace(970, 70, 11, o, y, m)) { std::printf("suzanne must keep its equal shares\n"); return 1; }
+      // round 6: the rule from 12 units on - suzanne's 16 units in the instantiation its equal shares chose (3 slots)
+      if (!ptw::seqUnitSplitByPlace(970, 70, 3, o, y, m) || o != 3 || y != 2 || m != 3) { std::printf("suzanne by place %d %d %d\n", o, y, m); return 1; }
+      if (ptw::seqUnitSplitByPlace(700, 70, 2, o, y, m)) { std::printf("11 units keep their equal shares\n"); return 1; }
+      if (ptw::seqUnitSplitByPlace(1060, 70, 3, o, y, m)) { std::printf("17 units by place would need a bigger instantiation\n"); return 1; }
       if (ptw::seqUnitSplitByPlace(4000, 70, 11, o, y, m)) { std::printf("63 units do not fit ten slots\n"); return 1; }
       std::printf("OK %ld\n", checked);
       return 0;
