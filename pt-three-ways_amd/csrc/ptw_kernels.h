@@ -90,6 +90,31 @@ __host__ __device__ inline bool seqUnitSplitByPlace(uint32_t ntri, int youngPerc
   return true;
 }
 
+// One-master kernels (seven workers: three pairs on SIMD 1-3 + one wave beside the master), scenes from 8 units on:
+// the same observation (profiles/r06y_*, 256 passes: suzanne 3 / 3 / 3 -> 3 / 2 / 1 +8.7 %, what the wave beside the
+// master holds does not matter there; ce 8 / 8 / 6 -> 9 / 6 / 9 +6 % in a new <9,7> instantiation, 10 / 7 / 3 and
+// 8 / 7 / 10 no better than equal shares; closed soups +2.6 % at 8 units ... +6 % at 25-57, never slower).  A unit
+// costs a younger wave 100 / youngPercent of what it costs an older or the master-side wave; of the shares o >= y,
+// o >= m with 3 o + 3 y + m >= U and o <= cap (and <= 10: twelve slots spill) the ones with the cheapest slowest wave,
+// then the smallest o, y, m.  Returns false - equal shares - when nothing fits.
+__host__ __device__ inline bool seqUnitSplitByPlaceOneMaster(uint32_t ntri, int youngPercent, int cap, int &uOld, int &uYoung, int &uMaster) {
+  const int U = static_cast<int>((ntri + 63u) / 64u);
+  if (U < 8 || youngPercent <= 0 || youngPercent >= 100) return false;
+  long best = -1;
+  for (int o = 1; o <= cap && o <= 10; ++o)
+    for (int y = 1; y <= o; ++y) {
+      int m = U - 3 * o - 3 * y;
+      if (m > o) continue;
+      if (m < 0) m = 0;
+      const long costY = (static_cast<long>(y) * 10000 + youngPercent - 1) / youngPercent; // in 1 / 100 units
+      long cost = static_cast<long>(o) * 100;
+      if (costY > cost) cost = costY;
+      const long key = ((cost * 16 + o) * 16 + y) * 16 + m;
+      if (best < 0 || key < best) best = key, uOld = o, uYoung = y, uMaster = m;
+    }
+  return best >= 0;
+}
+
 // Global (row-major, full-frame) index of local pixel l.
 __host__ __device__ inline uint32_t globalPixel(const TraceParams &p, uint32_t l) {
   if (p.rowStride == 1) return static_cast<uint32_t>(p.rowFirst) * static_cast<uint32_t>(p.width) + l;

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
 // (seqUnitSplitByPlace) - below 31 units only inside the instantiation the equal shares choose (a larger one
 // costs more than the shares bring: profiles/r06w_*).  LaunchHints::seqUnits sets them outright (tests, A/B
 // runs; what does not fit the waves' shares is streamed from memory).
-void seqUnitsFor(uint32_t ntri, int nA, int nB, int cap, const LaunchHints &hints, int &uO, int &uY, int &uM) {
+void seqUnitsFor(uint32_t ntri, int nA, int nB, int cap, const LaunchHints &hints, int &uO, int &uY, int &uM, bool pre = false) {
   int uA, uB;
   seqUnitSplit(ntri, nA, nB, 100, cap, uA, uB);
   uO = uY = uA, uM = uB;
@@ -268,6 +268,15 @@ void seqUnitsFor(uint32_t ntri, int nA, int nB, int cap, const LaunchHints &hint
       if (inst < capPlace) capPlace = inst;
     }
     (void)seqUnitSplitByPlace(ntri, PTW_SEQ_YOUNG_PERCENT, capPlace, uO, uY, uM);
+  } else if (nA == 6 && nB == 1 && (!pre || (ntri + 63u) / 64u < 31u)) { // (the prefilter's one-master kernels: only inside
+    // the equal shares' instantiation - suzanne +6.4 %; ce 9 / 6 / 9 needs its 12-slot kernel: -3.4 %, profiles/r06y_*)
+    int capPlace = cap;
+    if ((ntri + 63u) / 64u < 31u) { // the one-master instantiations: 1, 2, 3, 4, 6, 8, 9, 10, 12 slots
+      const int need = uA > uB ? uA : uB;
+      const int inst = need <= 4 ? need : need <= 6 ? 6 : need <= 8 ? 8 : need;
+      if (inst < capPlace) capPlace = inst;
+    }
+    (void)seqUnitSplitByPlaceOneMaster(ntri, PTW_SEQ_YOUNG_PERCENT, capPlace, uO, uY, uM);
   }
   const int o = hints.seqUnits[0], y = hints.seqUnits[1], m = hints.seqUnits[2];
   if ((o | y | m) != 0 && o >= 0 && y >= 0 && m >= 0 && o <= cap && y <= cap && m <= cap) uO = o, uY = y, uM = m;
@@ -278,7 +287,7 @@ hipError_t launchSeq(const TraceParams &pIn, const TraceBuffers &b, const Launch
   TraceParams p = pIn;
   if (WAVES > 1) {
     int uO, uY, uM;
-    seqUnitsFor(p.ntri, WAVES - MASTERS, MASTERS, SLOTS, hints, uO, uY, uM);
+    seqUnitsFor(p.ntri, WAVES - MASTERS, MASTERS, SLOTS, hints, uO, uY, uM, PRE);
     p.seqUnitsA = uO, p.seqUnitsY = uY, p.seqUnitsB = uM;
   }
   // (one wave per pass: the pick checksum is its own instantiation, see SeqCtx::picksOn)

@@ -12,7 +12,7 @@ namespace {
 template <bool PRE>
 hipError_t selectSeqOneMaster(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream) {
   int uO, uY, uM;
-  seqUnitsFor(p.ntri, 6, 1, 12, hints, uO, uY, uM);
+  seqUnitsFor(p.ntri, 6, 1, 12, hints, uO, uY, uM, PRE);
   const int need = std::max(uO, std::max(uY, uM));
   if (need <= 1) return launchSeqAuto<1, 7, 1, PRE>(p, b, hints, stream);
   if (need <= 2) return launchSeqAuto<2, 7, 1, PRE>(p, b, hints, stream);
@@ -20,6 +20,10 @@ hipError_t selectSeqOneMaster(const TraceParams &p, const TraceBuffers &b, const
   if (need <= 4) return launchSeqAuto<4, 7, 1, PRE>(p, b, hints, stream);
   if (need <= 6) return launchSeq<6, 7, false, false, 1, PRE>(p, b, hints, stream);
   if (need <= 8) return launchSeq<8, 7, false, false, 1, PRE>(p, b, hints, stream);
+  if constexpr (!PRE) { // (the shares by place of a large scene: ce 9 / 6 / 9; fp64 triangles only)
+    if (need <= 9) return launchSeq<9, 7, false, false, 1, PRE>(p, b, hints, stream);
+    if (need <= 10) return launchSeq<10, 7, false, false, 1, PRE>(p, b, hints, stream);
+  }
   return launchSeq<12, 7, false, false, 1, PRE>(p, b, hints, stream); // beyond 5376 the tail is streamed from memory
 }
 

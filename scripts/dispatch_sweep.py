@@ -33,6 +33,7 @@ if os.environ.get("SWEEP_SIZES"):      # e.g. SWEEP_SIZES=32,64 SWEEP_PASSES=384
     SIZES = [int(x) for x in os.environ["SWEEP_SIZES"].split(",")]
 if os.environ.get("SWEEP_PASSES"):
     PASSES = [int(x) for x in os.environ["SWEEP_PASSES"].split(",")]
+POLICIES = tuple(int(x) for x in os.environ.get("SWEEP_POLICIES", "0,1").split(","))
 
 
 def run(scene, cam_of, ntri, passes, policy, debug, extra):
@@ -88,6 +89,14 @@ def neighbours(ntri, passes, policy):
                 hi = min(11, (units - 2 * lo + 3) // 4)
                 if 2 * hi + 2 * lo + 2 * hi >= units and (hi, lo) != (eq, eq):
                     out.append((f"shares by place {hi}/{lo}/{hi}", dict(seq_units=(hi, lo, hi)), {}))
+        if not two and units >= 7:   # one master: three worker pairs + one wave beside the master
+            eq = (units + 6) // 7
+            if eq <= 10:
+                out.append((f"equal shares {eq}/{eq}/{eq}", dict(seq_units=(eq, eq, eq)), {}))
+                lo = max(1, (eq * 7 + 5) // 10)
+                rest = units - 3 * eq - 3 * lo
+                if rest <= eq and lo != eq:
+                    out.append((f"shares by place {eq}/{lo}/{max(rest, 0)}", dict(seq_units=(eq, lo, max(rest, 0))), {}))
     return out
 
 
@@ -102,7 +111,7 @@ def main():
 
         def cam_of(edge):
             return pkg.set_focus(pkg.look_at((0, 0.5, 7), (0, 0, 0), (0, 1, 0), edge, edge, 45.0), (0, 0, 0), 0.02)
-        for policy in (0, 1):
+        for policy in POLICIES:
             for passes in (PASSES if policy == 0 else [256]):
                 base = run(scene, cam_of, ntri, passes, policy, {}, {})
                 rows = neighbours(ntri, passes, policy)

@@ -3,8 +3,8 @@ without a device) - which kernel runs for a scene of N triangles and a launch of
 
 * monotone in N: a larger scene never gets a kernel with FEWER resident triangles per workgroup, and the families
   follow each other in one order (speculative / single wave -> worker waves);
-* the thresholds are where DESIGN.md says they are (64 / 128 triangles, more passes than CUs, 12 units for the
-  shares by place, the LDS budget of the shading tables);
+* the thresholds are where DESIGN.md says they are (64 / 128 triangles, more passes than CUs, 12 / 8 units for the
+  shares by place with two masters / one, the LDS budget of the shading tables);
 * every name the table can produce is a kernel the GPU suite holds to the oracle somewhere (the names are the ones
   ptw_kernel_stats.trace_kernel reports).
 """
@@ -54,7 +54,11 @@ def test_thresholds(pkg):
     assert plan(129, samples_per_pixel=257) == "traceSequential<1,6,lds,stack,2 masters>"
     assert plan(970, samples_per_pixel=512) == "traceSequential<3,6,lds,stack,2 masters>"     # BASELINE cfg3
     assert plan(3442, num_spheres=3, samples_per_pixel=1024) == "traceSequential<10,6,global,stack,2 masters>"  # cfg4
-    assert plan(3442, samples_per_pixel=256) == "traceSequential<8,7,global,stack>"
+    # one master: shares by place from 8 units on (below 31 inside the equal shares' instantiation); ce 9 / 6 / 9
+    assert plan(3442, samples_per_pixel=256) == "traceSequential<9,7,global,stack>"
+    assert plan(970, samples_per_pixel=256) == "traceSequential<3,7,lds,stack>"
+    assert plan(3700, samples_per_pixel=256) == "traceSequential<10,7,global,stack>"
+    assert plan(4600, samples_per_pixel=256) == "traceSequential<12,7,global,stack>"
     # shares by place (two masters) from 12 units of 64 triangles on; below 31 units they stay inside the instantiation
     # the equal shares choose: 17 units -> 3 slots (4 / 2 / 4 would need four), 30 -> 6 / 4 / 6 in the 6-slot kernel
     assert plan(17 * 64, samples_per_pixel=512) == "traceSequential<3,6,lds,stack,2 masters>"

@@ -274,7 +274,7 @@ def test_worker_wave_kernels_resolve_exact_ties_like_the_reference(pkg, ob, mast
     rgb, cnt, words, variant, _, picks = r3._render_with_stats(pkg, scene, cam, params, picks=True, seq_two_masters=masters)
     small = nbase == 140
     want = {1: "traceSequential<2,6,lds,stack,2 masters>" if small else "traceSequential<10,6,global,stack,2 masters>",
-            0: "traceSequential<1,7,lds,stack>" if small else "traceSequential<8,7,global,stack>"}[masters]
+            0: "traceSequential<1,7,lds,stack>" if small else "traceSequential<9,7,global,stack>"}[masters]
     assert variant == want, variant
     assert np.array_equal(cnt, ref_cnt)
     assert np.array_equal(words, ref_words), "a tie was resolved differently from the reference"

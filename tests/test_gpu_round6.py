@@ -215,8 +215,10 @@ ONE_MASTER_CASES = [
     (1000, "global", "traceSequential<3,7,global,stack>"),
     (1350, "lds", "traceSequential<4,7,lds,stack>"),
     (1700, "global", "traceSequential<4,7,global,stack>"),
-    (2500, "global", "traceSequential<6,7,global,stack>"),
-    (3400, "global", "traceSequential<8,7,global,stack>"),
+    (2000, "global", "traceSequential<6,7,global,stack>"),
+    (2500, "global", "traceSequential<8,7,global,stack>"),
+    (3400, "global", "traceSequential<9,7,global,stack>"),     # shares by the wave's place: 9 / 6 / 9 (54 units)
+    (3700, "global", "traceSequential<10,7,global,stack>"),    # 10 / 7 / 7
     (5600, "global", "traceSequential<12,7,global,stack>"),    # beyond 12 x 7 x 64 = 5 376 resident: a streamed tail
 ]
 

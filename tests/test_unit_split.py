@@ -57,6 +57,27 @@ PROGRAM = textwrap.dedent(r"""
       if (ptw::seqUnitSplitByPlace(700, 70, 2, o, y, m)) { std::printf("11 units keep their equal shares\n"); return 1; }
       if (ptw::seqUnitSplitByPlace(1060, 70, 3, o, y, m)) { std::printf("17 units by place would need a bigger instantiation\n"); return 1; }
       if (ptw::seqUnitSplitByPlace(4000, 70, 11, o, y, m)) { std::printf("63 units do not fit ten slots\n"); return 1; }
+      // round 6, third session: the one-master kernels (three worker pairs + one wave beside the master)
+      for (unsigned ntri = 129; ntri <= 6000; ntri += 5)
+        for (int cap : {1, 2, 3, 4, 6, 8, 9, 10, 12}) {
+          int o = -1, y = -1, m = -1;
+          const int U = (ntri + 63) / 64;
+          if (!ptw::seqUnitSplitByPlaceOneMaster(ntri, 70, cap, o, y, m)) {
+            if (o != -1 || y != -1 || m != -1) { std::printf("one master: outputs touched on refusal %u\n", ntri); return 1; }
+            const int c = cap < 10 ? cap : 10;
+            if (U >= 8 && 7 * c >= U) { std::printf("one master: refused although equal shares of %d fit: ntri %u\n", c, ntri); return 1; }
+            continue;
+          }
+          if (U < 8 || o > cap || o > 10 || y > o || m > o || y < 1 || m < 0) { std::printf("one master: ntri %u cap %d -> %d %d %d\n", ntri, cap, o, y, m); return 1; }
+          if (3 * o + 3 * y + m < U) { std::printf("one master loses triangles: ntri %u -> %d %d %d for %d\n", ntri, o, y, m, U); return 1; }
+          if (3 * o + 3 * y + m - U > 3) { std::printf("one master wasteful: ntri %u cap %d -> %d %d %d for %d\n", ntri, cap, o, y, m, U); return 1; }
+          ++checked;
+        }
+      if (!ptw::seqUnitSplitByPlaceOneMaster(970, 70, 3, o, y, m) || o != 3 || y != 2 || m != 1) { std::printf("suzanne, one master %d %d %d\n", o, y, m); return 1; }
+      if (!ptw::seqUnitSplitByPlaceOneMaster(3442, 70, 12, o, y, m) || o != 9 || y != 6 || m != 9) { std::printf("ce, one master %d %d %d\n", o, y, m); return 1; }
+      if (!ptw::seqUnitSplitByPlaceOneMaster(512, 70, 2, o, y, m) || o != 2 || y != 1 || m != 0) { std::printf("8 units, one master %d %d %d\n", o, y, m); return 1; }
+      if (ptw::seqUnitSplitByPlaceOneMaster(448, 70, 1, o, y, m)) { std::printf("7 units keep their equal shares\n"); return 1; }
+      if (ptw::seqUnitSplitByPlaceOneMaster(4500, 70, 12, o, y, m)) { std::printf("71 units do not fit ten slots\n"); return 1; }
       std::printf("OK %ld\n", checked);
       return 0;
     }
