@@ -29,7 +29,9 @@ extern "C" {
 
 /* 6 (round 6): PTW_ACCEL_PREFILTER and its known-answer entry ptw_scene_prefilter_records;
  * ptw_debug_options.seq_small_kernel = 3; seq_pairing / gang_groups retired (refused, layout kept). */
-#define PTW_ABI_VERSION 6
+/* 7 (round 6, third session): ptw_scene_unit_coherence and ptw_debug_options.seq_unit_ufirst (the new field takes
+ * the four bytes of padding before d_picks: the layout of v6 is unchanged). */
+#define PTW_ABI_VERSION 7
 
 typedef enum ptw_status {
   PTW_OK = 0,
@@ -213,6 +215,12 @@ int ptw_scene_view_of(const ptw_scene *scene, ptw_scene_view *out);
 int ptw_scene_prefilter_records(const ptw_scene *scene, float *out, uint64_t capacity_floats,
                                 uint64_t *needed_floats, int32_t *usable);
 
+/* The statistic behind ptw_debug_options.seq_unit_ufirst (host only, no device): the fraction of (ray, unit of 64
+ * consecutive triangles) pairs, over a fixed pseudo-random sample of rays starting on the scene's triangles, in
+ * which NO triangle of the unit passes the u test of src/dod/Scene.cpp:79-89.  Meshes whose faces follow each other
+ * in space score high (ce 0.7), random soups 0.  Decides a schedule, never a result. */
+int ptw_scene_unit_coherence(const ptw_scene *scene, double *out);
+
 /* ---- Camera ctor / setFocus, src/math/Camera.h:40-51 ------------------------------------ */
 int ptw_camera_look_at(const double eye[3], const double look_at[3], const double up[3],
                        int32_t width, int32_t height, double vertical_fov_degrees,
@@ -263,6 +271,10 @@ typedef struct ptw_debug_options {
   int32_t trace;                /* 1: ptw_context_calibrate prints its two timings to stderr          */
   int32_t intersect_accel;      /* ptw_context_intersect (the known-answer entry): 0 = the brute-force
                                    search, PTW_ACCEL_PREFILTER = through the fp32 prefilter - same hits */
+  int32_t seq_unit_ufirst;      /* worker-wave kernels: the unit-level u-first early-out of the worker waves
+                                   (a unit of 64 consecutive triangles none of which passes the u test of
+                                   src/dod/Scene.cpp:79-89 skips the rest of the test: same decisions, same
+                                   values): -1 the library's rule (ptw_scene_unit_coherence >= 0.4), 0 off, 1 on */
   /* Pick checksum (parity instrumentation, PTW_RNG_SEQUENTIAL only): a DEVICE pointer to
    * [pass][y][x] uint32 receiving, per sample, sum over the sample's intersect() calls r = 0, 1, ...
    * in the reference's call order of (r + 1) * (combined primitive index + 1) mod 2^32, a miss

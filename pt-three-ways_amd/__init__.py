@@ -125,7 +125,8 @@ class DebugOptions(C.Structure):
                 ("seq_small_kernel", C.c_int32), ("seq_units", C.c_int32 * 3),
                 ("pix_samples_per_lane", C.c_int32), ("pix_waves_per_simd", C.c_int32),
                 ("gang_groups", C.c_int32), ("fail_shard", C.c_int32), ("fail_collective", C.c_int32),
-                ("silent_shard", C.c_int32), ("trace", C.c_int32), ("intersect_accel", C.c_int32), ("d_picks", C.c_void_p)]
+                ("silent_shard", C.c_int32), ("trace", C.c_int32), ("intersect_accel", C.c_int32), ("seq_unit_ufirst", C.c_int32),
+                ("d_picks", C.c_void_p)]
 
 
 class DispatchQuery(C.Structure):
@@ -175,6 +176,7 @@ _sig("ptw_scene_build_named", C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_i
      C.POINTER(Camera))
 _sig("ptw_scene_view_of", C.c_int, C.c_void_p, C.POINTER(SceneView))
 _sig("ptw_dispatch_plan", C.c_int, C.POINTER(DispatchQuery), C.c_void_p, C.c_char_p, C.c_size_t)
+_sig("ptw_scene_unit_coherence", C.c_int, C.c_void_p, C.POINTER(C.c_double))
 _sig("ptw_scene_prefilter_records", C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int32))
 _sig("ptw_camera_look_at", C.c_int, _D3, _D3, _D3, C.c_int32, C.c_int32, C.c_double,
      C.POINTER(Camera))
@@ -346,6 +348,12 @@ class Scene:
         v = SceneView()
         _check(lib.ptw_scene_view_of(self._h, C.byref(v)))
         return v
+
+    def unit_coherence(self) -> float:
+        """ptw_scene_unit_coherence: how often a unit of 64 consecutive triangles fails the u test as a whole."""
+        out = C.c_double(0.0)
+        _check(lib.ptw_scene_unit_coherence(self._h, C.byref(out)))
+        return out.value
 
     def prefilter_records(self):
         """PTW_ACCEL_PREFILTER's fp32 pair records (ptw_scene_prefilter_records): ([npairs, 22] float32, usable)."""

@@ -73,6 +73,7 @@ void ptw_debug_defaults(ptw_debug_options *out) {
   std::memset(out, 0, sizeof *out);
   out->seq_two_masters = out->seq_pairing = out->seq_lds_tables = out->seq_small_kernel = -1;
   out->fail_shard = out->fail_collective = out->silent_shard = -1;
+  out->seq_unit_ufirst = -1;
 }
 
 void ptw_default_params(ptw_render_params *out) {
@@ -195,6 +196,16 @@ int ptw_scene_prefilter_records(const ptw_scene *scene, float *out, uint64_t cap
   if (usable) *usable = pre.usable ? 1 : 0;
   const uint64_t n = full < capacity_floats ? full : capacity_floats;
   for (uint64_t i = 0; i < n; ++i) out[i] = pre.pairs[i];
+  return PTW_OK;
+  PTW_GUARD_END
+}
+
+int ptw_scene_unit_coherence(const ptw_scene *scene, double *out) {
+  if (!scene || !out) return invalid("null pointer");
+  PTW_GUARD_BEGIN
+  const ptw_scene_view view = scene->builder.view();
+  const ptw::DeviceSceneData data = ptw::precomputeScene(view);
+  *out = ptw::unitUSkipFraction(data.triGeom.data(), view.num_triangles);
   return PTW_OK;
   PTW_GUARD_END
 }

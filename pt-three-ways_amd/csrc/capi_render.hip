@@ -81,6 +81,7 @@ struct ptw_context {
   // accelerated mode (PTW_ACCEL_PREFILTER): the fp32 pair records, built with the scene
   DeviceArray<float> triPacked;
   bool prefilterUsable = false;
+  bool unitsCoherent = false; // unitUSkipFraction(scene) >= kUnitUFirstThreshold: the worker waves' unit-level u-first early-out
   // SEQUENTIAL, scenes of at most 64 triangles, more passes than CUs: the small-scene kernel a timed trial chose
   // (ptw_debug_options.seq_small_kernel's values 1 / 2; 0 = none) and what it was measured for
   int seqSmallChoice = 0;
@@ -254,6 +255,7 @@ TraceParams makeTraceParams(const ptw_context &ctx, const ptw_camera &cam,
   t.rowFirst = 0;
   t.rowStride = 1;
   t.accel = p.accel;
+  t.seqUnitUFirst = ctx.debug.seq_unit_ufirst >= 0 ? (ctx.debug.seq_unit_ufirst != 0) : ctx.unitsCoherent;
 #if defined(PTW_PROFILE_PHASES) && PTW_PROFILE_PHASES
   if (const char *v = std::getenv("PTW_PIX_COUNT_SLOTS")) t.padA = v[0] == '1'; // (the prof build's lane-slot counter)
 #endif
@@ -606,6 +608,7 @@ int ptw_context_set_scene(ptw_context *ctx, const ptw_scene_view *scene) {
   const PrefilterData pre = buildPrefilter(data.triGeom.data(), scene->num_triangles, scene->sph_centre_radius, scene->num_spheres);
   ctx->triPacked.upload(pre.pairs.data(), pre.pairs.size(), nullptr);
   ctx->prefilterUsable = pre.usable;
+  ctx->unitsCoherent = unitUSkipFraction(data.triGeom.data(), scene->num_triangles) >= kUnitUFirstThreshold;
   check(hipStreamSynchronize(nullptr), "scene upload");
   ctx->ntri = scene->num_triangles;
   ctx->nsph = scene->num_spheres;

@@ -86,6 +86,8 @@ hipError_t dispatchSequential(const TraceParams &p, const TraceBuffers &b, const
                                                                       : p.npass > static_cast<uint32_t>(cusFor(hints));
   if (p.accel == PTW_ACCEL_PREFILTER) // (the separate mode: the worker lanes look in fp32 first)
     return mm ? launchSeqTwoMastersPrefilter(p, b, hints, stream) : launchSeqOneMasterPrefilter(p, b, hints, stream);
+  if (p.seqUnitUFirst) // (scenes whose units of 64 consecutive triangles mostly fail the u test as a whole)
+    return mm ? launchSeqTwoMastersUnit(p, b, hints, stream) : launchSeqOneMasterUnit(p, b, hints, stream);
   return mm ? launchSeqTwoMasters(p, b, hints, stream) : launchSeqOneMaster(p, b, hints, stream);
 }
 } // namespace

@@ -42,6 +42,9 @@ struct TraceParams {
   // arbiter serves the older wave first: round 4 measured the younger ones 35-40 % slower per triangle,
   // profiles/r04k_*): seqUnitsA is then the older wave's share.  Equal to seqUnitsA by default.
   int32_t seqUnitsY;
+  // ... and whether the worker waves try the unit-level u-first early-out (testTriangleUnit: scenes whose units of
+  // 64 consecutive triangles mostly fail the u test as a whole - host/precompute.h unitUSkipFraction)
+  int32_t seqUnitUFirst;
 };
 constexpr int kPixKernelAuto = 0, kPixKernelLockstep = 1, kPixKernelPersistent = 2;
 

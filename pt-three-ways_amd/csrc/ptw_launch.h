@@ -8,6 +8,7 @@
 //   seq_spec.hip      traceSequentialSpec                       four speculating waves per pass (<= 64 triangles)
 //   seq_worker.hip    traceSequential<SLOTS, 7, ...>            seven worker waves + one master
 //   seq_worker2.hip   traceSequential<SLOTS, 6, ..., 2 masters> six worker waves shared by two passes
+//   seq_worker_unit.hip, seq_worker2_unit.hip   the same two families with the unit-level u-first early-out
 //   seq_worker_pre.hip, seq_worker2_pre.hip   the same two families with the fp32 prefilter in the worker lanes
 //   perpixel.hip      tracePerPixel, tracePerPixelPersistent    PERPIXEL policy, brute force
 //   accel.hip         tracePerPixelBvh, tracePerPixelPrefilter  the separate accelerated modes
@@ -38,6 +39,10 @@ hipError_t launchSeqSingle(const TraceParams &p, const TraceBuffers &b, const La
                            int slots, bool reg);
 hipError_t launchSeqOneMaster(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream);
 hipError_t launchSeqTwoMasters(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream);
+// ... the same two families with the unit-level u-first early-out in the worker waves (seq_worker_unit.hip,
+// seq_worker2_unit.hip: scenes with TraceParams::seqUnitUFirst set)
+hipError_t launchSeqOneMasterUnit(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream);
+hipError_t launchSeqTwoMastersUnit(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream);
 // ... and the same two families with the fp32 prefilter in the worker lanes (seq_worker_pre.hip, seq_worker2_pre.hip:
 // PTW_ACCEL_PREFILTER under the SEQUENTIAL policy)
 hipError_t launchSeqOneMasterPrefilter(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream);

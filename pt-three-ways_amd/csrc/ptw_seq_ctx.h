@@ -121,8 +121,9 @@ constexpr int kRecEmission = 0, kRecDiffuse = 3, kRecDoubles = 6;
 // of slots against 50 per slot); the reference's fp64 test runs only for the slots whose rejection fp32 cannot
 // prove, on v0 / e1 / e2 fetched from memory by the lanes that need them.  Same hits, bit for bit.
 template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false, bool SPEC = false, int MASTERS = 1, bool PICKS = true,
-          bool PRE = false>
+          bool PRE = false, bool UNIT = false>
 struct SeqCtx {
+  static_assert(!UNIT || (WAVES > 1 && !PRE), "the unit-level u-first early-out exists for the plain worker-wave kernels");
   static_assert(!PRE || (WAVES > 1 && !REG && !SPEC), "the prefilter form exists for the worker-wave kernels");
   static constexpr int kPairs = (SLOTS + 1) / 2;
   Float2 pv0x[kPairs], pv0y[kPairs], pv0z[kPairs], pe1x[kPairs], pe1y[kPairs], pe1z[kPairs], pe2x[kPairs], pe2y[kPairs],
@@ -524,21 +525,32 @@ struct SeqCtx {
         }
       }
     }
+    // a worker wave holds 64 consecutive triangles per slot: for scenes whose units mostly fail the u test as a whole
+    // (decided on the host per scene, TraceParams::seqUnitUFirst) the dispatcher picks the UNIT instantiation - the
+    // unit-level early-out - and the fused test for the others.  (One kernel with both loops behind a wave-uniform
+    // flag was measured first: the second copy of the unrolled loop cost either path 2-4 %, profiles/r06ab_*.)
+    constexpr bool unitUFirst = UNIT;
 #pragma unroll
     for (int s = 0; s < (PRE ? 0 : SLOTS); ++s) {
       // (wave-uniform: this wave's share of the scene ends at myUnits.  A guard, not a `break`: with a
       // second loop exit the compiler stops unrolling from nine slots on, indexes the slot arrays
       // at run time and moves them to scratch memory)
       if (WAVES > 1 && s >= myUnits) continue;
-      testTriangle(o, d, mk(v0x[s], v0y[s], v0z[s]), mk(e1x[s], e1y[s], e1z[s]),
-                   mk(e2x[s], e2y[s], e2z[s]), nsph + slotTriangle(s),
-                   bestT, bestIdx, bestDet);
+      if constexpr (UNIT)
+        testTriangleUnit(o, d, mk(v0x[s], v0y[s], v0z[s]), mk(e1x[s], e1y[s], e1z[s]),
+                         mk(e2x[s], e2y[s], e2z[s]), nsph + slotTriangle(s), bestT, bestIdx, bestDet);
+      else
+        testTriangle(o, d, mk(v0x[s], v0y[s], v0z[s]), mk(e1x[s], e1y[s], e1z[s]),
+                     mk(e2x[s], e2y[s], e2z[s]), nsph + slotTriangle(s),
+                     bestT, bestIdx, bestDet);
     }
     // rare: more triangles than resident slots -> stream the remainder from memory
     if (!REG && p->ntri > residentTriangles())
       for (uint32_t k = residentTriangles() + tid; k < p->ntri; k += kThreads) {
         const double *g = triGeom + 9 * static_cast<size_t>(k);
-        testTriangle(o, d, ld3(g), ld3(g + 3), ld3(g + 6), nsph + k, bestT, bestIdx, bestDet);
+        // (a wave's lanes hold 64 consecutive triangles here too)
+        if (unitUFirst) testTriangleUnit(o, d, ld3(g), ld3(g + 3), ld3(g + 6), nsph + k, bestT, bestIdx, bestDet);
+        else testTriangle(o, d, ld3(g), ld3(g + 3), ld3(g + 6), nsph + k, bestT, bestIdx, bestDet);
       }
 
     // wave reduction: lexicographic min of (t, idx)

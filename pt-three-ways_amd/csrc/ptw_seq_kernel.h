@@ -12,7 +12,8 @@ namespace ptw {
 using namespace ptwd;
 namespace {
 
-template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false, int MASTERS = 1, bool PICKS = true, bool PRE = false>
+template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false, int MASTERS = 1, bool PICKS = true, bool PRE = false,
+          bool UNIT = false>
 __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void traceSequential(
     const TraceParams p, const double *__restrict__ triGeom,
     const TriShade *__restrict__ triShade, const SphereRec *__restrict__ spheres,
@@ -20,7 +21,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 64 : 64 * (WAVES + MASTERS)) void trac
     uint32_t *__restrict__ mtState, uint32_t *__restrict__ mtPos, double *__restrict__ stage,
     uint32_t *__restrict__ words, unsigned long long *__restrict__ rayCounters, uint32_t *__restrict__ picks,
     const float *__restrict__ triPacked) {
-  using Ctx = SeqCtx<SLOTS, WAVES, LDS_TABLES, REG, false, MASTERS, PICKS, PRE>;
+  using Ctx = SeqCtx<SLOTS, WAVES, LDS_TABLES, REG, false, MASTERS, PICKS, PRE, UNIT>;
   extern __shared__ __attribute__((aligned(64))) unsigned char ldsRaw[];
   (void)triShade;
   const int depthSlots = p.maxDepth > 0 ? p.maxDepth : 1;
@@ -282,7 +283,7 @@ void seqUnitsFor(uint32_t ntri, int nA, int nB, int cap, const LaunchHints &hint
   if ((o | y | m) != 0 && o >= 0 && y >= 0 && m >= 0 && o <= cap && y <= cap && m <= cap) uO = o, uY = y, uM = m;
 }
 
-template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false, int MASTERS = 1, bool PRE = false>
+template <int SLOTS, int WAVES, bool LDS_TABLES, bool REG = false, int MASTERS = 1, bool PRE = false, bool UNIT = false>
 hipError_t launchSeq(const TraceParams &pIn, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream) {
   TraceParams p = pIn;
   if (WAVES > 1) {
@@ -291,10 +292,10 @@ hipError_t launchSeq(const TraceParams &pIn, const TraceBuffers &b, const Launch
     p.seqUnitsA = uO, p.seqUnitsY = uY, p.seqUnitsB = uM;
   }
   // (one wave per pass: the pick checksum is its own instantiation, see SeqCtx::picksOn)
-  auto kernel = WAVES == 1 && !b.picks ? traceSequential<SLOTS, WAVES, LDS_TABLES, REG, MASTERS, WAVES != 1, PRE>
-                                       : traceSequential<SLOTS, WAVES, LDS_TABLES, REG, MASTERS, true, PRE>;
+  auto kernel = WAVES == 1 && !b.picks ? traceSequential<SLOTS, WAVES, LDS_TABLES, REG, MASTERS, WAVES != 1, PRE, UNIT>
+                                       : traceSequential<SLOTS, WAVES, LDS_TABLES, REG, MASTERS, true, PRE, UNIT>;
   setVariant("traceSequential<%d,%d,%s,%s%s%s>", SLOTS, WAVES, LDS_TABLES ? "lds" : "global", REG ? "reg" : "stack",
-             MASTERS == 2 ? ",2 masters" : "", PRE ? ",prefilter" : "");
+             MASTERS == 2 ? ",2 masters" : "", PRE ? ",prefilter" : UNIT ? ",unit" : "");
   if (hints.dryRun) return hipSuccess;
   const size_t lds = seqLdsBytes(WAVES, p.maxDepth, LDS_TABLES, p.ntri, p.nmat, p.nsph, MASTERS);
   if (lds > 48 * 1024) { // per launch: the attribute belongs to the current device's copy of the kernel
@@ -312,12 +313,12 @@ hipError_t launchSeq(const TraceParams &pIn, const TraceBuffers &b, const Launch
 
 // ... with the shading tables in LDS when they fit (LaunchHints::seqLdsTables == 0: global memory
 // whatever their size - the tests reach the global-table instantiations with small scenes that way)
-template <int SLOTS, int WAVES, int MASTERS = 1, bool PRE = false>
+template <int SLOTS, int WAVES, int MASTERS = 1, bool PRE = false, bool UNIT = false>
 hipError_t launchSeqAuto(const TraceParams &p, const TraceBuffers &b, const LaunchHints &hints, hipStream_t stream) {
   const size_t tables = seqLdsBytes(WAVES, p.maxDepth, true, p.ntri, p.nmat, p.nsph, MASTERS);
   if (hints.seqLdsTables != 0 && tables <= kLdsTableBudget)
-    return launchSeq<SLOTS, WAVES, true, false, MASTERS, PRE>(p, b, hints, stream);
-  return launchSeq<SLOTS, WAVES, false, false, MASTERS, PRE>(p, b, hints, stream);
+    return launchSeq<SLOTS, WAVES, true, false, MASTERS, PRE, UNIT>(p, b, hints, stream);
+  return launchSeq<SLOTS, WAVES, false, false, MASTERS, PRE, UNIT>(p, b, hints, stream);
 }
 
 } // namespace

@@ -93,6 +93,38 @@ __device__ __forceinline__ void testTriangleUFirst(d3 o, d3 d, d3 v0, d3 e1, d3 
   }
 }
 
+// The same test for the worker waves of the SEQUENTIAL kernels, in which the 64 lanes of a wave test 64 CONSECUTIVE
+// triangles (one unit) against one ray.  The faces of a mesh follow each other in space, so for most rays NO triangle
+// of a unit passes the u test (scripts/sim/unit_skip_stats.py: ce 67-70 % of the units, suzanne 17-30 %; 2.7 % of the
+// triangles pass it) - and then the wave skips qVec, v and t for the unit: one ballot and one branch.  Same decisions,
+// same values as testTriangle (the argument above); a lane whose determinant is too small computes a garbage u that
+// `ok` masks.  Returns nothing: updates (bestT, bestIdx, bestDet) like testTriangle.
+// Taken when TraceParams::seqUnitUFirst says the scene is of that kind (host/precompute.h unitUSkipFraction >= 0.4:
+// ce two masters +10 %, one master +4 %; suzanne, where 17-30 % of the units skip, -1 %; random soups -1 ... -4 %:
+// profiles/r06aa_*); the other scenes run the fused test.
+__device__ __forceinline__ void testTriangleUnit(d3 o, d3 d, d3 v0, d3 e1, d3 e2, uint32_t idx,
+                                                 double &bestT, uint32_t &bestIdx, double &bestDet) {
+  const d3 pVec = cross(d, e2);
+  const double det = dot(e1, pVec);
+  const bool ok = !(__builtin_fabs(det) < kEpsilon);
+  const double invDet = rcp(det);
+  const d3 tVec = o - v0;
+  const double u = dot(tVec, pVec) * invDet;
+  const bool pu = ok & !((u < 0.0) | (u > 1.0));
+  if (__builtin_amdgcn_ballot_w64(pu) == 0) return; // wave-uniform: nobody in this unit gets past u
+  if (pu) {
+    const d3 qVec = cross(tVec, e1);
+    const double v = dot(d, qVec) * invDet;
+    if ((v < 0.0) | (u + v > 1)) return;
+    const double t = dot(e2, qVec) * invDet;
+    if (t > kEpsilon && t < bestT) {
+      bestT = t;
+      bestIdx = idx;
+      bestDet = det;
+    }
+  }
+}
+
 // Two fp32 values in one 64-bit register pair: the operand type of v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
 // (the conservative fp32 prefilter of PTW_ACCEL_PREFILTER: host/prefilter.h).
 typedef float Float2 __attribute__((ext_vector_type(2)));

@@ -102,6 +102,7 @@ void parseDebug(Options &o, const std::string &spec) {
     else if (name == "pix_waves_per_simd") o.debug.pix_waves_per_simd = v;
     else if (name == "gang_groups") o.debug.gang_groups = v;
     else if (name == "trace") o.debug.trace = v;
+    else if (name == "seq_unit_ufirst") o.debug.seq_unit_ufirst = v;
     else if (name == "share_device") o.shareDevice = v;
     else usageError("Unknown --debug option " + name);
   }

@@ -2,6 +2,7 @@
 #include "vec3.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <stdexcept>
 
@@ -95,6 +96,48 @@ void seedMt19937(uint32_t seed, uint32_t state[624]) {
     const uint32_t prev = state[i - 1];
     state[i] = 1812433253u * (prev ^ (prev >> 30)) + i;
   }
+}
+
+double unitUSkipFraction(const double *g, uint32_t ntri) {
+  const uint32_t units = (ntri + 63u) / 64u;
+  if (units < 2) return 0.0;
+  uint64_t state = 0x9e3779b97f4a7c15ull; // splitmix64: a fixed sample, the same on every host
+  auto next = [&state]() {
+    uint64_t z = (state += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+  };
+  auto uniform = [&next]() { return static_cast<double>(next() >> 11) * (1.0 / 9007199254740992.0); };
+  const uint32_t perRay = units < 32 ? units : 32;
+  uint64_t looked = 0, skipped = 0;
+  for (int r = 0; r < 64; ++r) {
+    // origin: a point inside a random triangle; direction: uniform on the sphere
+    const double *a = g + 9 * static_cast<size_t>(next() % ntri);
+    const double o[3] = {a[0] + (a[3] + a[6]) / 3.0, a[1] + (a[4] + a[7]) / 3.0, a[2] + (a[5] + a[8]) / 3.0};
+    double d[3], n2;
+    do {
+      for (double &c : d) c = 2.0 * uniform() - 1.0;
+      n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    } while (n2 > 1.0 || n2 < 1e-4);
+    const uint32_t first = static_cast<uint32_t>(next() % units);
+    for (uint32_t j = 0; j < perRay; ++j) {
+      const uint32_t unit = (first + j * (units / perRay)) % units;
+      bool any = false;
+      for (uint32_t k = unit * 64u; k < unit * 64u + 64u && k < ntri && !any; ++k) {
+        const double *t = g + 9 * static_cast<size_t>(k);
+        const double *e1 = t + 3, *e2 = t + 6;
+        const double p[3] = {d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0]};
+        const double det = e1[0] * p[0] + e1[1] * p[1] + e1[2] * p[2];
+        if (std::fabs(det) < 1e-7) continue;
+        const double u = ((o[0] - t[0]) * p[0] + (o[1] - t[1]) * p[1] + (o[2] - t[2]) * p[2]) / det;
+        any = !(u < 0.0 || u > 1.0);
+      }
+      ++looked;
+      skipped += any ? 0 : 1;
+    }
+  }
+  return static_cast<double>(skipped) / static_cast<double>(looked);
 }
 
 } // namespace ptw

@@ -35,8 +35,9 @@ def test_struct_layouts(pkg):
     assert C.sizeof(pkg.RenderParams) == 17 * 4   # v4: + pix_kernel
     assert C.sizeof(pkg.KernelStats) == 48 + 64
     assert C.sizeof(pkg.RenderOptions) == 64       # v5: reserved[3] -> reserved + the debug pointer
-    assert C.sizeof(pkg.DebugOptions) == 72        # v6: + intersect_accel
-    assert pkg.lib.ptw_abi_version() == 6
+    assert C.sizeof(pkg.DebugOptions) == 72        # v6: + intersect_accel; v7: seq_unit_ufirst in the padding
+    assert pkg.DebugOptions.d_picks.offset == 64 and pkg.DebugOptions.seq_unit_ufirst.offset == 60
+    assert pkg.lib.ptw_abi_version() == 7
     p = pkg.default_params()
     assert (p.width, p.height, p.preview, p.samples_per_pixel, p.max_depth, p.first_bounce_u,
             p.first_bounce_v, p.seed, p.rng_policy) == (1920, 1080, 0, 40, 5, 4, 4, 0, 0)

@@ -135,7 +135,7 @@ def test_two_master_natural_dispatch_more_passes_than_cus(pkg, ob, ntri, nsph, k
 
 
 @pytest.mark.parametrize("name,edge,spp,kernel", [("suzanne", 16, 6, "traceSequential<3,6,lds,stack,2 masters"),
-                                                  ("ce", 6, 5, "traceSequential<10,6,global,stack,2 masters")])
+                                                  ("ce", 6, 5, "traceSequential<10,6,global,stack,2 masters,unit")])   # (",unit": the unit-level u-first early-out, round 6)
 def test_two_master_kernels_on_the_baseline_scenes(pkg, ob, name, edge, spp, kernel):
     """suzanne and ce - the scenes of cfg3 / cfg4 - directly against the oracle under the two-master
     kernels they run there.  On ce neither the radiance nor the RNG word counts can depend on which
@@ -174,7 +174,7 @@ def test_a_dropped_unit_of_triangles_shows_in_the_pick_checksum(pkg, ob):
     sparams = pkg.default_params(width=6, height=4, samples_per_pixel=3, seed=8)
     _, _, swords, spicks = ob.oracle_render_picks(soup.view(), scam, sparams, threads=4)
     good = _render_with_stats(pkg, soup, scam, sparams, picks=True, seq_two_masters=1)
-    assert good[3].startswith("traceSequential<10,6,global,stack,2 masters"), good[3]
+    assert good[3] == "traceSequential<10,6,global,stack,2 masters>", good[3]
     assert np.array_equal(good[2], swords) and np.array_equal(good[5], spicks)
     unit = pick_helpers.find_sensitive_unit(pkg, ob, soup, scam, sparams)
     bad = _render_with_stats(pkg, pick_helpers.scene_without_unit(pkg, soup, unit), scam, sparams, picks=True,

@@ -237,8 +237,8 @@ def test_rccl_peer_that_exits_is_an_error_not_a_hang(tmp_path):
 # ---- exact ties in the worker-wave kernels (the round-4 pick and LDS-atomic reduction) -------------
 @pytest.mark.parametrize("nbase", [140, 1100])
 @pytest.mark.parametrize("masters", [1, 0])
-@pytest.mark.parametrize("spp", [3, 4])
-def test_worker_wave_kernels_resolve_exact_ties_like_the_reference(pkg, ob, masters, spp, nbase):
+@pytest.mark.parametrize("spp,ufirst", [(3, -1), (4, -1), (3, 1)])
+def test_worker_wave_kernels_resolve_exact_ties_like_the_reference(pkg, ob, masters, spp, nbase, ufirst):
     """Scene::intersect scans the primitives in insertion order with a strict `<` (Scene.cpp:31,95,118):
     of several primitives hit at EXACTLY the same distance the one inserted first wins - and its
     material decides the path.  A scene of 140 large triangles, each with a copy 20 indices later (the
@@ -271,11 +271,11 @@ def test_worker_wave_kernels_resolve_exact_ties_like_the_reference(pkg, ob, mast
     params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=21)
     ref_rgb, ref_cnt, ref_words, ref_picks = ob.oracle_render_picks(scene.view(), cam, params, threads=4)
     import test_gpu_round3 as r3
-    rgb, cnt, words, variant, _, picks = r3._render_with_stats(pkg, scene, cam, params, picks=True, seq_two_masters=masters)
+    rgb, cnt, words, variant, _, picks = r3._render_with_stats(pkg, scene, cam, params, picks=True, seq_two_masters=masters, seq_unit_ufirst=ufirst)
     small = nbase == 140
     want = {1: "traceSequential<2,6,lds,stack,2 masters>" if small else "traceSequential<10,6,global,stack,2 masters>",
             0: "traceSequential<1,7,lds,stack>" if small else "traceSequential<9,7,global,stack>"}[masters]
-    assert variant == want, variant
+    assert variant == (want[:-1] + ",unit>" if ufirst == 1 else want), variant
     assert np.array_equal(cnt, ref_cnt)
     assert np.array_equal(words, ref_words), "a tie was resolved differently from the reference"
     assert np.array_equal(picks, ref_picks), "a tie went to another primitive than in the reference"

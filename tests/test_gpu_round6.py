@@ -75,7 +75,7 @@ def test_cfg4_full_width_prefix(pkg, ob):
     params = pkg.default_params(width=w, height=h, samples_per_pixel=2, seed=1, row_begin=0, row_end=rows)
     (rgb, cnt, words, picks, kernel), (r_rgb, r_cnt, r_words, r_picks) = _render_async_then_oracle(
         pkg, ob, scene, cam, params, threads=2, seq_two_masters=1)
-    assert kernel == "traceSequential<10,6,global,stack,2 masters>", kernel
+    assert kernel == "traceSequential<10,6,global,stack,2 masters,unit>", kernel   # (ce: the unit-level u-first early-out)
     assert np.array_equal(cnt, r_cnt) and int(cnt.sum()) == 2 * w * rows and int(cnt[rows:].sum()) == 0
     assert int(np.count_nonzero(words != r_words)) == 0
     assert int(np.count_nonzero(picks != r_picks)) == 0
@@ -179,7 +179,9 @@ def test_obj_scene_of_24k_triangles_matches_oracle(pkg, ob, big_scene, mode):
         ref_rgb, ref_cnt, ref_words, ref_picks = ob.oracle_render_picks(big_scene.view(), cam, params, threads=3)
         debug = dict(seq_two_masters=1) if mode.endswith("two-masters") else {}
         rgb, cnt, words, kernel, _, picks = r3._render_with_stats(pkg, big_scene, cam, params, picks=True, **debug)
-        want = "traceSequential<11,6,global,stack,2 masters>" if debug else "traceSequential<12,7,global,stack>"
+        # (",unit": 24 202 small triangles - every unit fails the u test as a whole for most rays; the streamed tail
+        # takes the early-out too)
+        want = "traceSequential<11,6,global,stack,2 masters,unit>" if debug else "traceSequential<12,7,global,stack,unit>"
         assert kernel == want, kernel
         assert np.array_equal(picks, ref_picks), "a ray hit another primitive than in the oracle"
         assert len(np.unique(ref_picks)) > 20   # (the picks do tell the triangles apart here)
@@ -479,3 +481,49 @@ def test_speculative_kernels_fold_matches_oracle_on_random_shapes(pkg, ob, monke
     assert np.array_equal(words, ref_words), c
     assert np.array_equal(picks, ref_picks), c
     assert rel_err(rgb, ref_rgb) < TOL, c
+
+
+# ---- the worker waves' unit-level u-first early-out (round 6, third session; ptw_debug_options.seq_unit_ufirst) ----
+# The library switches it on by a host-side statistic of the scene (ptw_scene_unit_coherence >= 0.4: ce yes, suzanne and
+# the random soups of this suite no), so the soup tests above run the fused test; here every worker-wave instantiation
+# runs with the early-out FORCED ON (and, for the scenes that get it by the rule, forced off): radiance, every sample's
+# RNG word count and every sample's pick checksum against the oracle.
+UFIRST_CASES = [(n, t, k + ">", 1) for n, t, k in __import__("test_gpu_round3").TWO_MASTER_CASES] + \
+               [(n, t, k, 0) for n, t, k in ONE_MASTER_CASES if ",7," in k]
+
+
+@pytest.mark.parametrize("ntri,tables,kernel,masters", UFIRST_CASES)
+def test_worker_wave_kernels_with_the_unit_early_out_forced_on_match_oracle(pkg, ob, ntri, tables, kernel, masters):
+    import test_gpu_round3 as r3
+    debug = dict(seq_two_masters=masters, seq_unit_ufirst=1)
+    if tables == "global" and ntri < 1400:
+        debug["seq_lds_tables"] = 0
+    scene, cam = r3._soup(pkg, ntri, 2, seed=7 * ntri + masters, w=5, h=3)
+    params = pkg.default_params(width=5, height=3, samples_per_pixel=3, seed=12)
+    ref_rgb, ref_cnt, ref_words, ref_picks = ob.oracle_render_picks(scene.view(), cam, params, threads=4)
+    rgb, cnt, words, variant, _, picks = r3._render_with_stats(pkg, scene, cam, params, picks=True, **debug)
+    assert variant == kernel[:-1] + ",unit>", variant
+    assert np.array_equal(cnt, ref_cnt) and np.array_equal(words, ref_words)
+    assert np.array_equal(picks, ref_picks), "a ray hit another primitive than in the oracle"
+    assert rel_err(rgb, ref_rgb) < TOL
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("ce", 8, 6, 2), ("suzanne", 24, 16, 3)])
+@pytest.mark.parametrize("masters", [0, 1])
+def test_unit_early_out_on_and_off_write_the_same_samples(pkg, ob, name, w, h, spp, masters):
+    """The two forms of the worker waves' triangle test on the meshes themselves (ce: the scene the rule switches it
+    on for, 66 % of its units fail the u test as a whole; suzanne: 18 %): the same image bytes, word counts and picks
+    - and the oracle's."""
+    import test_gpu_round3 as r3
+    scene = pkg.Scene()
+    cam = scene.build_named(name, w, h)
+    assert (scene.unit_coherence() >= 0.4) == (name == "ce")
+    params = pkg.default_params(width=w, height=h, samples_per_pixel=spp, seed=3)
+    ref_rgb, ref_cnt, ref_words, ref_picks = ob.oracle_render_picks(scene.view(), cam, params, threads=8)
+    out = [r3._render_with_stats(pkg, scene, cam, params, picks=True, seq_two_masters=masters, seq_unit_ufirst=u) for u in (0, 1, -1)]
+    for (rgb, cnt, words, variant, _, picks), unit in zip(out, (False, True, name == "ce")):
+        assert variant.startswith("traceSequential<") and (",2 masters" in variant) == bool(masters), variant
+        assert variant.endswith(",unit>") == unit, variant
+        assert np.array_equal(words, ref_words) and np.array_equal(picks, ref_picks) and np.array_equal(cnt, ref_cnt)
+        assert rel_err(rgb, ref_rgb) < TOL
+    assert out[0][0].tobytes() == out[1][0].tobytes() == out[2][0].tobytes()
