@@ -374,7 +374,9 @@ int ptw_context_get_stats(ptw_context *ctx, ptw_kernel_stats *out, int32_t reset
 /* Which kernel would run?  The dispatch rules of the library (csrc/dispatch.hip and the family launchers) for
  * a scene of the given size and a launch of `samples_per_pixel` passes, WITHOUT a device or a launch: writes
  * the kernel's name - the string ptw_kernel_stats.trace_kernel reports after a real render - into `out`.
- * `debug` may be NULL (the dispatcher decides).  scripts/dispatch_sweep.py and the CPU tests use it. */
+ * `debug` may be NULL (the dispatcher decides).  scripts/dispatch_sweep.py and the CPU tests use it.  One decision
+ * needs the scene itself and is not in the plan: the `,unit` form of the worker-wave kernels (ptw_scene_unit_coherence
+ * >= 0.4) - `debug->seq_unit_ufirst = 1` names it. */
 typedef struct ptw_dispatch_query {
   uint32_t num_triangles, num_spheres, num_materials;
   int32_t max_depth;         /* RenderParams::maxDepth (5)                                        */

@@ -716,6 +716,7 @@ int ptw_dispatch_plan(const ptw_dispatch_query *q, const ptw_debug_options *debu
   t.npass = static_cast<uint32_t>(q->samples_per_pixel);
   t.rngPolicy = q->rng_policy;
   t.accel = q->accel;
+  t.seqUnitUFirst = debug && debug->seq_unit_ufirst == 1; // (the rule itself needs the scene: ptw_scene_unit_coherence)
   t.pixKernel = q->pix_kernel == PTW_PIX_KERNEL_LOCKSTEP ? kPixKernelLockstep : kPixKernelPersistent;
   TraceBuffers b;
   std::memset(&b, 0, sizeof b);

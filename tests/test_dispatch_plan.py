@@ -72,6 +72,11 @@ def test_thresholds(pkg):
     assert plan(40, seq_small_kernel=3) == "traceSequentialSpec<no cross-pixel candidate>"
     assert plan(40, samples_per_pixel=512, seq_small_kernel=4) == "traceSequentialSpec<2 waves>"
     assert plan(200, samples_per_pixel=512, seq_lds_tables=0) == "traceSequential<1,6,global,stack,2 masters>"
+    # the unit-level u-first form of the worker-wave kernels is the scene's decision (ptw_scene_unit_coherence): forced
+    assert plan(3442, samples_per_pixel=1024, seq_unit_ufirst=1) == "traceSequential<10,6,global,stack,2 masters,unit>"   # cfg4
+    assert plan(3442, samples_per_pixel=256, seq_unit_ufirst=1) == "traceSequential<9,7,global,stack,unit>"
+    assert plan(100, samples_per_pixel=256, seq_unit_ufirst=1) == "traceSequential<2,1,lds,stack>"     # (worker waves only)
+    assert plan(3442, samples_per_pixel=1024, accel=2, seq_unit_ufirst=1).endswith(",prefilter>")
 
 
 def test_perpixel_table(pkg):
@@ -103,6 +108,11 @@ def test_every_planned_kernel_is_tested_on_the_gpu(pkg):
                 produced.add(pkg.dispatch_plan(n, samples_per_pixel=passes, **extra))
                 if n > 128:
                     produced.add(pkg.dispatch_plan(n, samples_per_pixel=passes, accel=2, **extra))
+                    # ... and its unit-level u-first form (picked by the scene's statistic): held to the oracle by
+                    # test_worker_wave_kernels_with_the_unit_early_out_forced_on_match_oracle over the same case lists
+                    unit = pkg.dispatch_plan(n, samples_per_pixel=passes, seq_unit_ufirst=1, **extra)
+                    assert unit.replace(",unit>", ">") == pkg.dispatch_plan(n, samples_per_pixel=passes, **extra)
     text = "".join(p.read_text() for p in (ROOT / "tests").glob("test_gpu_*.py"))
+    assert "UFIRST_CASES = [(n, t, k + \">\", 1) for n, t, k in __import__(\"test_gpu_round3\").TWO_MASTER_CASES]" in text
     missing = [k for k in sorted(produced) if k.rstrip(">") not in text and k not in text]
     assert not missing, missing
