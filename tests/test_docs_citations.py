@@ -56,6 +56,7 @@ def test_design_describes_what_ships_and_stays_short():
     assert len(design.encode()) <= 30 * 1024, len(design.encode())
     assert "LAB.md" in design and (ROOT / "LAB.md").exists()
     for kernel_file in ("seq_spec.hip", "seq_single.hip", "seq_worker.hip", "seq_worker2.hip", "perpixel.hip", "accel.hip",
+                        "seq_worker_unit.hip", "seq_worker2_unit.hip", "seq_worker_pre.hip", "seq_worker2_pre.hip",
                         "resolve_kat.hip", "dispatch.hip"):
         assert kernel_file in design and (ROOT / "pt-three-ways_amd" / "csrc" / kernel_file).exists(), kernel_file
 
