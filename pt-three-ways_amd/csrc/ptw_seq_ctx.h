@@ -537,7 +537,7 @@ struct SeqCtx {
       // at run time and moves them to scratch memory)
       if (WAVES > 1 && s >= myUnits) continue;
       if constexpr (UNIT)
-        testTriangleUnit(o, d, mk(v0x[s], v0y[s], v0z[s]), mk(e1x[s], e1y[s], e1z[s]),
+        testTriangleUnit<true>(o, d, mk(v0x[s], v0y[s], v0z[s]), mk(e1x[s], e1y[s], e1z[s]),
                          mk(e2x[s], e2y[s], e2z[s]), nsph + slotTriangle(s), bestT, bestIdx, bestDet);
       else
         testTriangle(o, d, mk(v0x[s], v0y[s], v0z[s]), mk(e1x[s], e1y[s], e1z[s]),
@@ -549,7 +549,7 @@ struct SeqCtx {
       for (uint32_t k = residentTriangles() + tid; k < p->ntri; k += kThreads) {
         const double *g = triGeom + 9 * static_cast<size_t>(k);
         // (a wave's lanes hold 64 consecutive triangles here too)
-        if (unitUFirst) testTriangleUnit(o, d, ld3(g), ld3(g + 3), ld3(g + 6), nsph + k, bestT, bestIdx, bestDet);
+        if (unitUFirst) testTriangleUnit<false>(o, d, ld3(g), ld3(g + 3), ld3(g + 6), nsph + k, bestT, bestIdx, bestDet);
         else testTriangle(o, d, ld3(g), ld3(g + 3), ld3(g + 6), nsph + k, bestT, bestIdx, bestDet);
       }
 

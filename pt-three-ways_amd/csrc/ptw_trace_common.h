@@ -102,6 +102,10 @@ __device__ __forceinline__ void testTriangleUFirst(d3 o, d3 d, d3 v0, d3 e1, d3 
 // Taken when TraceParams::seqUnitUFirst says the scene is of that kind (host/precompute.h unitUSkipFraction >= 0.4:
 // ce two masters +10 %, one master +4 %; suzanne, where 17-30 % of the units skip, -1 %; random soups -1 ... -4 %:
 // profiles/r06aa_*); the other scenes run the fused test.
+// V_BALLOT: a second ballot after v - on ce 97 % of the (ray, unit) pairs have no lane past u AND v - skips t for the
+// unit as well (the resident slots: ce two masters +4.5 %, one master +5 %; not the streamed tail, where it measured
+// +1 / -3 %: profiles/r06ag_*).
+template <bool V_BALLOT>
 __device__ __forceinline__ void testTriangleUnit(d3 o, d3 d, d3 v0, d3 e1, d3 e2, uint32_t idx,
                                                  double &bestT, uint32_t &bestIdx, double &bestDet) {
   const d3 pVec = cross(d, e2);
@@ -112,7 +116,24 @@ __device__ __forceinline__ void testTriangleUnit(d3 o, d3 d, d3 v0, d3 e1, d3 e2
   const double u = dot(tVec, pVec) * invDet;
   const bool pu = ok & !((u < 0.0) | (u > 1.0));
   if (__builtin_amdgcn_ballot_w64(pu) == 0) return; // wave-uniform: nobody in this unit gets past u
-  if (pu) {
+  if constexpr (V_BALLOT) {
+    d3 qVec = mk(0, 0, 0);
+    bool puv = false;
+    if (pu) {
+      qVec = cross(tVec, e1);
+      const double v = dot(d, qVec) * invDet;
+      puv = !((v < 0.0) | (u + v > 1));
+    }
+    if (__builtin_amdgcn_ballot_w64(puv) == 0) return; // ... nor past v
+    if (puv) {
+      const double t = dot(e2, qVec) * invDet;
+      if (t > kEpsilon && t < bestT) {
+        bestT = t;
+        bestIdx = idx;
+        bestDet = det;
+      }
+    }
+  } else if (pu) {
     const d3 qVec = cross(tVec, e1);
     const double v = dot(d, qVec) * invDet;
     if ((v < 0.0) | (u + v > 1)) return;
